@@ -1,0 +1,69 @@
+"""pytest config: registers the ``gpu`` marker, puts the product package directory on sys.path.
+
+``-m "not gpu"`` runs here on CPU (oracle vs golden vectors, host logic, C-ABI symbol check,
+gloo world_size-2 tests); ``-m gpu`` runs on the MI355X box and calls the HIP path through
+the C-ABI. /root/reference is only read by tests marked ``needs_reference`` (auto-skipped
+when it is absent, i.e. on the GPU box).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "imbalanced-regression_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / driver)")
+    config.addinivalue_line("markers", "needs_reference: reads /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    from oracle import refshim
+    have_ref = refshim.available()
+    skip_ref = pytest.mark.skip(reason="/root/reference not present")
+    for item in items:
+        if "needs_reference" in item.keywords and not have_ref:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+def relerr(a, b, floor=0.0):
+    """max |a-b| / max(|b|, floor) — the 1e-5-relative bar of BASELINE.json's north_star."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor if floor > 0 else 1e-30)))
+
+
+def assert_close(a, b, rtol=1e-5, atol_scale=1e-6, msg=""):
+    """|a-b| <= rtol*|b| + atol_scale*max|b| element-wise: the north_star's 1e-5-relative bar,
+    with an absolute term of 1e-6 of the array's scale for elements that are themselves the result
+    of a cancellation (e.g. (x-m1)*s+m2 ~ 0 from O(1) operands: a 1-ulp operand difference is
+    6e-8 of the scale, not of the element)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape, msg)
+    if a.size == 0:
+        return
+    assert np.array_equal(np.isnan(a), np.isnan(b)), f"NaN pattern differs {msg}"
+    scale = float(np.nanmax(np.abs(b))) if np.isfinite(b).any() else 0.0
+    tol = rtol * np.abs(b) + atol_scale * scale
+    bad = np.abs(a - b) > tol
+    bad &= ~np.isnan(a)
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.where(bad, np.abs(a - b), 0)), a.shape)
+        raise AssertionError(f"{msg}: {int(bad.sum())}/{a.size} outside tol; worst at {i}: got {a[i]!r} want {b[i]!r}")

@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in this directory by RUNNING THE UPSTREAM REFERENCE.
+
+Run in the build container only (needs /root/reference):  python tests/golden/gen_golden.py
+The reference modules are imported through ``oracle/refshim.py`` (``.cuda()`` -> identity,
+stub torchvision). Outputs are committed as small ``.npz`` fixtures; the GPU box never
+sees /root/reference, only these files. Environment the vectors were produced under is
+recorded in ``MANIFEST.json`` (torch / numpy / scipy versions = the de-facto pin of the
+reference's unpinned dependencies).
+
+Every array named ``ref_*`` is an output of reference code; every ``in_*`` is an input.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import scipy
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import refshim  # noqa: E402
+
+torch.set_num_threads(4)
+BUFFERS = ("epoch", "running_mean", "running_var", "running_mean_last_epoch",
+           "running_var_last_epoch", "smoothed_mean_last_epoch",
+           "smoothed_var_last_epoch", "num_samples_tracked")
+WINDOW_GRID = [("gaussian", 5, 2), ("gaussian", 5, 1), ("gaussian", 9, 1), ("gaussian", 9, 2),
+               ("gaussian", 3, 0.5), ("triang", 5, 1), ("triang", 9, 2), ("laplace", 5, 2),
+               ("laplace", 9, 1.5), ("gaussian", 1, 2)]
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    return path
+
+
+def gen_windows(ref):
+    out = {}
+    for i, (k, ks, s) in enumerate(WINDOW_GRID):
+        with refshim.cuda_identity():
+            out[f"ref_fds_{i}"] = ref.fds.FDS._get_kernel_window(k, ks, s).numpy()
+        out[f"ref_lds_{i}"] = np.asarray(ref.utils.get_lds_kernel_window(k, ks, s), dtype=np.float64)
+    out["grid"] = np.array([f"{k},{ks},{s}" for k, ks, s in WINDOW_GRID])
+    save("windows.npz", **out)
+
+
+LDS_CONFIGS = [("sqrt_inv", True, "gaussian", 5, 2), ("sqrt_inv", False, "gaussian", 5, 2),
+               ("inverse", False, "gaussian", 5, 2), ("inverse", True, "gaussian", 9, 1),
+               ("inverse", True, "triang", 9, 1), ("sqrt_inv", True, "laplace", 7, 1.5),
+               ("sqrt_inv", True, "gaussian", 9, 1), ("none", False, "gaussian", 5, 2)]
+
+
+def gen_lds():
+    import pandas as pd
+    df = pd.read_csv(os.path.join(refshim.REFERENCE_ROOT, "agedb-dir/data/agedb.csv"))
+    ages = df[df["split"] == "train"]["age"].values.astype(np.int64)
+    rng = np.random.default_rng(7)
+    # synthetic long-tailed IMDB-WIKI-like label set incl. ages > 120 (clipped to bin 120)
+    synth = np.clip(np.round(np.abs(rng.normal(0, 18, 20000)) + 20), 0, 140).astype(np.int64)
+    synth[:5] = [0, 120, 121, 139, 1]
+    frac = np.round(rng.uniform(0, 125, 3000), 1)          # non-integer labels -> int() truncation
+    sets = {"agedb": ages, "synth": synth, "frac": frac, "tiny": np.array([5, 5, 7], dtype=np.int64)}
+    out = {}
+    for sname, labels in sets.items():
+        out[f"in_labels_{sname}"] = labels
+        for ci, (rw, lds, k, ks, s) in enumerate(LDS_CONFIGS):
+            w = refshim.prepare_weights(labels, reweight=rw, lds=lds, lds_kernel=k, lds_ks=ks, lds_sigma=s)
+            if w is None:
+                out[f"ref_w_{sname}_{ci}"] = np.zeros((0,), np.float32)
+                continue
+            assert all(type(x) is np.float32 for x in w[:4]), type(w[0])
+            out[f"ref_w_{sname}_{ci}"] = np.asarray(w, dtype=np.float32)
+    out["configs"] = np.array([f"{rw},{int(lds)},{k},{ks},{s}" for rw, lds, k, ks, s in LDS_CONFIGS])
+    save("lds_weights.npz", **out)
+    # known-answer prefixes quoted in SURVEY.md §8c
+    w0 = out["ref_w_agedb_0"]
+    return hashlib.sha256(w0.tobytes()).hexdigest()[:16]
+
+
+def make_epoch_inputs(rng, n, c, start, num, epoch, variant):
+    """Synthetic labels/features exercising the quirks of SURVEY Appendix A."""
+    labels = np.clip(np.round(np.abs(rng.normal(0, 0.25 * num, n)) + start), 0, num + 6)
+    if variant == "boundary_absent":          # A.3: out-of-range rows but no boundary label
+        labels[labels == start] = start + 1
+        labels[labels == num - 1] = num - 2
+        labels[:6] = [start - 1, start - 2, num, num + 3, start + 2, start + 2]
+    elif variant == "boundary_present":
+        labels[:8] = [start, start - 1, start - 2, num - 1, num, num + 3, start, num - 1]
+    labels = np.maximum(labels, 0).astype(np.float32)
+    feats = (np.abs(rng.normal(0, 1, (n, c))) * 0.5 + 0.01 * labels[:, None]).astype(np.float32)
+    feats[:, 3] = 0.0                          # dead channel: zero variance, zero mean (A.9)
+    feats[:, 5] = 0.37109375                   # constant non-zero column (exact in f32)
+    one = start + 7                            # single-sample bin (A.9): biased var = 0
+    labels[labels == one] = one + 1
+    labels[n // 2] = one
+    if epoch == 2:
+        feats[:, 8] = F32(1.0) + F32(1e-4) * rng.normal(0, 1, n).astype(np.float32)   # tight column
+    return feats, labels
+
+
+F32 = np.float32
+FDS_CASES = [
+    dict(name="imdb", subdir="imdb-wiki-dir", n=500, c=40, variant="plain",
+         kw=dict(bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9)),
+    dict(name="agedb", subdir="agedb-dir", n=400, c=24, variant="boundary_present",
+         kw=dict(bucket_num=30, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=9, sigma=1, momentum=0.9)),
+    dict(name="absent", subdir="agedb-dir", n=300, c=16, variant="boundary_absent",
+         kw=dict(bucket_num=24, bucket_start=3, start_update=0, start_smooth=1, kernel="triang", ks=5, sigma=1, momentum=0.9)),
+    dict(name="nomomentum", subdir="imdb-wiki-dir", n=300, c=16, variant="boundary_present",
+         kw=dict(bucket_num=20, bucket_start=0, start_update=1, start_smooth=2, kernel="laplace", ks=3, sigma=1.5, momentum=None)),
+]
+N_EPOCHS = 5
+SMOOTH_B = 48
+
+
+def gen_fds_traces():
+    for case in FDS_CASES:
+        rng = np.random.default_rng(sum(map(ord, case["name"])))
+        kw = dict(feature_dim=case["c"], **case["kw"])
+        R = refshim.make_fds(case["subdir"], **kw)
+        out = {"kw": np.array(json.dumps(kw))}
+        for epoch in range(N_EPOCHS):
+            feats, labels = make_epoch_inputs(rng, case["n"], case["c"], kw["bucket_start"], kw["bucket_num"], epoch, case["variant"])
+            # --- smooth() on the first SMOOTH_B rows (fwd + autograd) with the tables as they are now
+            xb = feats[:SMOOTH_B].copy()
+            lb = labels[:SMOOTH_B, None].copy()
+            gy = rng.normal(0, 1, xb.shape).astype(np.float32)
+            xt = torch.tensor(xb, requires_grad=True)
+            with refshim.cuda_identity():
+                yt = R.smooth(xt.clone(), torch.tensor(lb), epoch)
+            if yt.requires_grad:
+                yt.backward(torch.tensor(gy))
+                gx = xt.grad.numpy().copy()
+            else:
+                gx = gy.copy()
+            out[f"e{epoch}_in_x"] = xb
+            out[f"e{epoch}_in_labels_b"] = lb
+            out[f"e{epoch}_in_gy"] = gy
+            out[f"e{epoch}_ref_smooth"] = yt.detach().numpy().copy()
+            out[f"e{epoch}_ref_gx"] = gx
+            for k in BUFFERS:       # tables smooth() saw (lets a checker feed identical tables)
+                out[f"e{epoch}_pre_{k}"] = getattr(R, k).detach().numpy().copy()
+            # --- epoch tail: train.py:280-281
+            with refshim.cuda_identity():
+                R.update_last_epoch_stats(epoch)
+                for k in BUFFERS:
+                    out[f"e{epoch}_mid_{k}"] = getattr(R, k).detach().numpy().copy()
+                R.update_running_stats(torch.tensor(feats), torch.tensor(labels), epoch)
+            out[f"e{epoch}_in_feats"] = feats
+            out[f"e{epoch}_in_labels"] = labels
+            out[f"e{epoch}_alias"] = np.array(R.running_mean_last_epoch is R.running_mean)
+            for k in BUFFERS:
+                out[f"e{epoch}_post_{k}"] = getattr(R, k).detach().numpy().copy()
+        save(f"fds_trace_{case['name']}.npz", **out)
+
+
+def gen_bins():
+    """A.3 examples + randoms: row -> bin index as implied by which rows the reference touches.
+    Derived by running reference ``smooth`` with tables that shift every touched row by (bin+1)."""
+    ref_cases = [([1, 2, 5, 5, 11, 12], 3, 10), ([1, 2, 3, 9, 11, 12], 3, 10), ([0, 99, 100, 150, 50], 0, 100),
+                 ([0, 98, 100, 150, 50], 0, 100), ([4.5, 4.0, 8.99, 9.0, 9.5, 3.0, 2.5], 3, 10)]
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        start, num = int(rng.integers(0, 4)), int(rng.integers(8, 40))
+        ref_cases.append((list(rng.integers(0, num + 4, 64).astype(float)), start, num))
+    out = {}
+    for i, (lab, start, num) in enumerate(ref_cases):
+        nb = num - start
+        R = refshim.make_fds("imdb-wiki-dir", feature_dim=2, bucket_num=num, bucket_start=start)
+        R.running_mean_last_epoch.zero_(); R.running_var_last_epoch.fill_(1)
+        R.smoothed_var_last_epoch.fill_(1)
+        R.smoothed_mean_last_epoch.copy_(torch.arange(1, nb + 1, dtype=torch.float32)[:, None].expand(nb, 2))
+        lab_t = torch.tensor(lab, dtype=torch.float32)[:, None]
+        with refshim.cuda_identity():
+            y = R.smooth(torch.zeros(len(lab), 2), lab_t, 5)
+        out[f"in_labels_{i}"] = lab_t.numpy()
+        out[f"params_{i}"] = np.array([start, num])
+        out[f"ref_bins_{i}"] = (y[:, 0].numpy().round().astype(np.int32) - 1)
+    out["n"] = np.array(len(ref_cases))
+    save("bin_index.npz", **out)
+
+
+def gen_calibrate(ref):
+    rng = np.random.default_rng(11)
+    out = {}
+    c = 32
+    cases = []
+    m1, m2 = rng.normal(0, 1, c).astype(np.float32), rng.normal(0, 1, c).astype(np.float32)
+    v1, v2 = rng.uniform(0.01, 2, c).astype(np.float32), rng.uniform(0.01, 2, c).astype(np.float32)
+    cases.append((m1, v1, m2, v2, 0.1, 10))                      # all columns
+    v1z = v1.copy(); v1z[[2, 9]] = 0
+    cases.append((m1, v1z, m2, v2, 0.1, 10))                     # some v1 == 0
+    cases.append((m1, np.full(c, 1e-13, np.float32), m2, v2, 0.1, 10))   # sum(v1) < 1e-10
+    v2w = v2.copy(); v2w[:4] = [1e-6, 1e6, -1.0, 0.0]
+    cases.append((m1, v1, m2, v2w, 0.1, 10))                     # both clip edges, negative v2
+    cases.append((m1, v1, m2, v2, 0.5, 2))                       # STS-B style clip
+    for i, (a, b, cc, d, lo, hi) in enumerate(cases):
+        x = rng.normal(0, 1, (9, c)).astype(np.float32)
+        y = ref.utils.calibrate_mean_var(torch.tensor(x.copy()), torch.tensor(a), torch.tensor(b),
+                                         torch.tensor(cc), torch.tensor(d), lo, hi)
+        out.update({f"in_x_{i}": x, f"in_m1_{i}": a, f"in_v1_{i}": b, f"in_m2_{i}": cc, f"in_v2_{i}": d,
+                    f"clip_{i}": np.array([lo, hi]), f"ref_y_{i}": y.numpy()})
+    out["n"] = np.array(len(cases))
+    save("calibrate.npz", **out)
+
+
+LOSS_VARIANTS = [("mse", {}), ("l1", {}), ("focal_mse", {}), ("focal_mse", {"activate": "tanh", "beta": 0.3, "gamma": 2}),
+                 ("focal_l1", {}), ("focal_l1", {"activate": "tanh", "beta": 0.3, "gamma": 2}),
+                 ("huber", {}), ("huber", {"beta": 0.5})]
+
+
+def gen_losses(ref):
+    rng = np.random.default_rng(5)
+    out = {}
+    for b in (1, 8, 256, 1000):
+        x = rng.normal(35, 12, (b, 1)).astype(np.float32)
+        y = np.round(rng.uniform(0, 100, (b, 1))).astype(np.float32)
+        w = rng.uniform(0.2, 4, (b, 1)).astype(np.float32)
+        x[0] = y[0]                                  # exact zero error: sign(0)/abs'(0) conventions
+        out[f"in_x_{b}"], out[f"in_y_{b}"], out[f"in_w_{b}"] = x, y, w
+        for vi, (kind, extra) in enumerate(LOSS_VARIANTS):
+            for use_w in (0, 1):
+                xt = torch.tensor(x, requires_grad=True)
+                fn = getattr(ref.loss, f"weighted_{kind}_loss")
+                loss = fn(xt, torch.tensor(y), torch.tensor(w) if use_w else None, **extra)
+                loss.backward()
+                out[f"ref_loss_{b}_{vi}_{use_w}"] = loss.detach().numpy()
+                out[f"ref_grad_{b}_{vi}_{use_w}"] = xt.grad.numpy().copy()
+    out["variants"] = np.array([json.dumps([k, e]) for k, e in LOSS_VARIANTS])
+    save("losses.npz", **out)
+
+
+def gen_resnet():
+    """Seeded reference resnet50 forward on CPU fp32 (resnet.py:127-153): pins architecture,
+    init order (same torch RNG stream) and the (pred, encoding) contract."""
+    torch.manual_seed(1234)
+    kw = dict(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
+              kernel="gaussian", ks=5, sigma=2, momentum=0.9)
+    model = refshim.make_resnet50("imdb-wiki-dir", **kw)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    t = torch.tensor([[31.0], [64.0]])
+    model.train()
+    with torch.no_grad(), refshim.cuda_identity():
+        pred, enc = model(x, t, 0)
+    model.eval()
+    with torch.no_grad():
+        pred_eval = model(x)
+    sd = model.state_dict()
+    keys = list(sd.keys())
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    save("resnet50_forward.npz", ref_pred_train=pred.numpy(), ref_enc_train=enc.numpy(),
+         ref_pred_eval=pred_eval.numpy(), keys=np.array(keys), ref_param_sums=sums,
+         shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]),
+         n_params=np.array(sum(p.numel() for p in model.parameters())))
+
+
+def main():
+    ref = refshim.load("imdb-wiki-dir")
+    gen_windows(ref)
+    sha = gen_lds()
+    gen_fds_traces()
+    gen_bins()
+    gen_calibrate(ref)
+    gen_losses(ref)
+    gen_resnet()
+    manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
+                "agedb_sqrtinv_lds_g52_sha256_prefix": sha,
+                "files": sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))}
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print(json.dumps(manifest, indent=1))
+
+
+if __name__ == "__main__":
+    main()
