@@ -1,0 +1,605 @@
+// FDS kernels for MI355X / gfx950 (CDNA4).  Hand-written HIP; compiled with -ffp-contract=off.
+// Reference behaviour replaced: imdb-wiki-dir/fds.py (all) + utils.py:97-107; see include/dir_hip.h.
+//
+// Every kernel here is HBM/launch bound (no dense contraction), so the design rules are the
+// streaming ones: 16-byte-per-lane coalesced rows, row-uniform table indices in SGPRs,
+// float64 register accumulators, wavefront-shuffle / ballot based grouping, no atomics on the
+// data path (bit-reproducible results), grids sized >> 256 CUs.
+#include "dir_common.h"
+
+// =============================================================================================
+// K1: labels -> bins
+// =============================================================================================
+__global__ void __launch_bounds__(DIR_TPB)
+fds_label_flags_kernel(const float* __restrict__ labels, int n, float lo, float hi, uint32_t* flags) {
+    uint32_t f = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        f |= dir_label_flag_bits(labels[i], lo, hi);
+    f = dir_wave_or(f);
+    if ((threadIdx.x & (DIR_WAVE - 1)) == 0 && f) atomicOr(flags, f);
+}
+
+__global__ void __launch_bounds__(DIR_TPB)
+fds_assign_bins_kernel(const float* __restrict__ labels, int n, float lo, float hi,
+                       const uint32_t* __restrict__ flags, int32_t* __restrict__ bins) {
+    const uint32_t f = *flags;
+    const bool has_lo = f & DIR_FLAG_HAS_LO, has_hi = f & DIR_FLAG_HAS_HI;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        bins[i] = dir_bin_of(labels[i], lo, hi, has_lo, has_hi);
+}
+
+static int check_buckets(int bucket_start, int bucket_num) {
+    return (bucket_num - bucket_start) >= 1 ? DIR_OK : DIR_EINVAL;
+}
+
+extern "C" int dir_fds_label_flags(const float* labels, int n, int bucket_start, int bucket_num,
+                                   uint32_t* flags, dir_stream_t stream) {
+    DIR_RETURN_IF(!labels || !flags || n < 0, DIR_EINVAL);
+    DIR_RETURN_IF(check_buckets(bucket_start, bucket_num), DIR_EINVAL);
+    if (n == 0) return DIR_OK;
+    int grid = dir_cdiv(n, DIR_TPB); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(fds_label_flags_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream),
+                       labels, n, (float)bucket_start, (float)(bucket_num - 1), flags);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_fds_assign_bins(const float* labels, int n, int bucket_start, int bucket_num,
+                                   const uint32_t* flags, int32_t* bins, dir_stream_t stream) {
+    DIR_RETURN_IF(!labels || !flags || !bins || n < 0, DIR_EINVAL);
+    DIR_RETURN_IF(check_buckets(bucket_start, bucket_num), DIR_EINVAL);
+    if (n == 0) return DIR_OK;
+    int grid = dir_cdiv(n, DIR_TPB); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(fds_assign_bins_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream),
+                       labels, n, (float)bucket_start, (float)(bucket_num - 1), flags, bins);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_fds_bin_index(const float* labels, int n, int bucket_start, int bucket_num,
+                                 int32_t* bins, uint32_t* flags, dir_stream_t stream) {
+    DIR_RETURN_IF(!flags, DIR_EINVAL);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t), dir_s(stream));
+    if (e != hipSuccess) return (int)e;
+    int rc = dir_fds_label_flags(labels, n, bucket_start, bucket_num, flags, stream);
+    if (rc) return rc;
+    return dir_fds_assign_bins(labels, n, bucket_start, bucket_num, flags, bins, stream);
+}
+
+// =============================================================================================
+// K2: per-bin (count, mean, M2) in one streaming pass
+// =============================================================================================
+// Stage G1-G3: stable counting sort of the row indices by bin (rows with bin < 0 dropped).
+//   tile  = GROUP_TILE consecutive rows handled by ONE wavefront (so ranks inside a tile come from
+//           ballots in program order: stable and deterministic without atomics on the data path);
+// Stage P : every "piece" (<= PIECE_ROWS sorted rows of one bin) x (column tile) is reduced in
+//           float64 registers around the shift K = first row of the bin;
+// Stage C : pieces of a bin are combined in index order -> (count, mean, M2).
+#define GROUP_TILE 1024
+#define PIECE_ROWS 128
+#define PIECE_UNROLL 8
+
+struct ScatterWs {            // carved from the caller's workspace (all 256-B aligned)
+    int32_t* tile_hist;       // [ntiles][nb]   counts, then exclusive prefix over tiles
+    int32_t* offsets;         // [nb+1]         start of each bin in perm
+    int32_t* bin_piece0;      // [nb+1]         first piece of each bin
+    int32_t* npieces;         // [1]
+    int32_t* perm;            // [n]            row indices grouped by bin
+    int32_t* piece_bin;       // [maxpieces]
+    int32_t* piece_p0;        // [maxpieces]
+    int32_t* piece_p1;        // [maxpieces]
+    double*  partials;        // [maxpieces][2][C]
+    int ntiles, maxpieces;
+    size_t bytes;
+};
+
+static ScatterWs carve_ws(void* base, int n, int C, int nb) {
+    ScatterWs w;
+    w.ntiles = dir_cdiv(n > 0 ? n : 1, GROUP_TILE);
+    w.maxpieces = dir_cdiv(n > 0 ? n : 1, PIECE_ROWS) + nb;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = dir_align_up(off + bytes, 256); return o; };
+    char* b = static_cast<char*>(base);
+    size_t o_hist = take(sizeof(int32_t) * (size_t)w.ntiles * nb);
+    size_t o_off = take(sizeof(int32_t) * (nb + 1));
+    size_t o_bp = take(sizeof(int32_t) * (nb + 1));
+    size_t o_np = take(sizeof(int32_t));
+    size_t o_perm = take(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    size_t o_pb = take(sizeof(int32_t) * (size_t)w.maxpieces);
+    size_t o_p0 = take(sizeof(int32_t) * (size_t)w.maxpieces);
+    size_t o_p1 = take(sizeof(int32_t) * (size_t)w.maxpieces);
+    size_t o_part = take(sizeof(double) * (size_t)w.maxpieces * 2 * C);
+    w.tile_hist = (int32_t*)(b + o_hist); w.offsets = (int32_t*)(b + o_off);
+    w.bin_piece0 = (int32_t*)(b + o_bp); w.npieces = (int32_t*)(b + o_np);
+    w.perm = (int32_t*)(b + o_perm); w.piece_bin = (int32_t*)(b + o_pb);
+    w.piece_p0 = (int32_t*)(b + o_p0); w.piece_p1 = (int32_t*)(b + o_p1);
+    w.partials = (double*)(b + o_part);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t dir_fds_scatter_stats_workspace(int n, int C, int nb) {
+    if (n < 0 || C <= 0 || nb <= 0) return 0;
+    return carve_ws(nullptr, n, C, nb).bytes;
+}
+
+// G1: one wavefront per tile; LDS histogram.
+__global__ void __launch_bounds__(DIR_WAVE)
+fds_group_hist_kernel(const int32_t* __restrict__ bins, int n, int nb, int32_t* __restrict__ tile_hist) {
+    extern __shared__ __attribute__((aligned(16))) int32_t hist[];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int b = lane; b < nb; b += DIR_WAVE) hist[b] = 0;
+    __syncthreads();
+    const int r0 = tile * GROUP_TILE;
+    for (int r = r0 + lane; r < min(n, r0 + GROUP_TILE); r += DIR_WAVE) {
+        const int b = bins[r];
+        if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);        // LDS integer atomic: order-free
+    }
+    __syncthreads();
+    for (int b = lane; b < nb; b += DIR_WAVE) tile_hist[(size_t)tile * nb + b] = hist[b];
+}
+
+// G2: single workgroup. tile_hist -> exclusive prefix over tiles (per bin); offsets; piece table.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_group_scan_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int maxpieces,
+                      int32_t* __restrict__ offsets, int32_t* __restrict__ bin_piece0,
+                      int32_t* __restrict__ npieces, int32_t* __restrict__ piece_bin,
+                      int32_t* __restrict__ piece_p0, int32_t* __restrict__ piece_p1) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sh[];     // totals[nb+1], pieces[nb+1]
+    int32_t* tot = sh;
+    int32_t* pcs = sh + (nb + 1);
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        int run = 0;
+        for (int t = 0; t < ntiles; ++t) {                 // coalesced across b
+            const int c = tile_hist[(size_t)t * nb + b];
+            tile_hist[(size_t)t * nb + b] = run;
+            run += c;
+        }
+        tot[b] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                // nb is a few hundred at most
+        int o = 0, p = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int c = tot[b];
+            offsets[b] = o; bin_piece0[b] = p;
+            tot[b] = o; pcs[b] = p;
+            o += c; p += (c + PIECE_ROWS - 1) / PIECE_ROWS;
+        }
+        offsets[nb] = o; bin_piece0[nb] = p; tot[nb] = o; pcs[nb] = p;
+        *npieces = p;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        const int o0 = tot[b], o1 = tot[b + 1];
+        int k = pcs[b];
+        for (int p0 = o0; p0 < o1; p0 += PIECE_ROWS, ++k) {
+            if (k < maxpieces) { piece_bin[k] = b; piece_p0[k] = p0; piece_p1[k] = min(p0 + PIECE_ROWS, o1); }
+        }
+    }
+}
+
+// G3: one wavefront per tile; stable placement through ballots.
+__global__ void __launch_bounds__(DIR_WAVE)
+fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb,
+                       const int32_t* __restrict__ tile_prefix, const int32_t* __restrict__ offsets,
+                       int32_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) int32_t cursor[];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int b = lane; b < nb; b += DIR_WAVE) cursor[b] = offsets[b] + tile_prefix[(size_t)tile * nb + b];
+    __syncthreads();
+    const int r0 = tile * GROUP_TILE;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int c = 0; c < GROUP_TILE; c += DIR_WAVE) {
+        const int r = r0 + c + lane;
+        int b = (r < n) ? bins[r] : -1;
+        if (b >= nb) b = -1;
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b0 = __shfl(b, leader, DIR_WAVE);
+            const unsigned long long mask = __ballot(b == b0);
+            const int base = cursor[b0];
+            __syncthreads();                               // all lanes have read before the bump
+            if (b == b0) perm[base + __popcll(mask & lt)] = r;
+            if (lane == leader) cursor[b0] = base + __popcll(mask);
+            __syncthreads();
+            todo &= ~mask;
+        }
+        if (r0 + c + DIR_WAVE >= n) break;
+    }
+}
+
+// P: piece x column-tile partial sums in float64 registers. VEC = 4 (16 B per lane) or 1.
+template <int VEC> struct FVec;
+template <> struct FVec<4> { using T = float4; };
+template <> struct FVec<1> { using T = float; };
+template <int VEC> __device__ __forceinline__ void fvec_get(const typename FVec<VEC>::T& v, float (&o)[VEC]);
+template <> __device__ __forceinline__ void fvec_get<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void fvec_get<1>(const float& v, float (&o)[1]) { o[0] = v; }
+
+template <int VEC>
+__global__ void __launch_bounds__(DIR_TPB)
+fds_piece_sums_kernel(const float* __restrict__ feats, int C,
+                      const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets,
+                      const int32_t* __restrict__ npieces, const int32_t* __restrict__ piece_bin,
+                      const int32_t* __restrict__ piece_p0, const int32_t* __restrict__ piece_p1,
+                      double* __restrict__ partials) {
+    using V = typename FVec<VEC>::T;
+    const int k = blockIdx.x;
+    if (k >= *npieces) return;
+    const int col = (blockIdx.y * DIR_TPB + threadIdx.x) * VEC;
+    if (col >= C) return;
+    const int b = piece_bin[k], p0 = piece_p0[k], p1 = piece_p1[k];      // block-uniform (SGPRs)
+    float kf[VEC];
+    fvec_get<VEC>(*reinterpret_cast<const V*>(feats + (size_t)perm[offsets[b]] * C + col), kf);
+    double kd[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { kd[j] = (double)kf[j]; s1[j] = 0.0; s2[j] = 0.0; }
+    int p = p0;
+    for (; p + PIECE_UNROLL <= p1; p += PIECE_UNROLL) {
+        V v[PIECE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PIECE_UNROLL; ++u)              // 8 independent 16-B loads in flight per lane
+            v[u] = *reinterpret_cast<const V*>(feats + (size_t)perm[p + u] * C + col);
+#pragma unroll
+        for (int u = 0; u < PIECE_UNROLL; ++u) {
+            float x[VEC]; fvec_get<VEC>(v[u], x);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const double d = (double)x[j] - kd[j]; s1[j] += d; s2[j] += d * d; }
+        }
+    }
+    for (; p < p1; ++p) {
+        float x[VEC]; fvec_get<VEC>(*reinterpret_cast<const V*>(feats + (size_t)perm[p] * C + col), x);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const double d = (double)x[j] - kd[j]; s1[j] += d; s2[j] += d * d; }
+    }
+    double* o1 = partials + ((size_t)k * 2 + 0) * C + col;
+    double* o2 = partials + ((size_t)k * 2 + 1) * C + col;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { o1[j] = s1[j]; o2[j] = s2[j]; }
+}
+
+// C: combine the pieces of each bin in index order.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_combine_kernel(const float* __restrict__ feats, int C, int nb,
+                   const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets,
+                   const int32_t* __restrict__ bin_piece0, const double* __restrict__ partials,
+                   double* __restrict__ count, double* __restrict__ mean, double* __restrict__ m2) {
+    const int b = blockIdx.x;
+    const int col = blockIdx.y * DIR_TPB + threadIdx.x;
+    const int o0 = offsets[b], cnt = offsets[b + 1] - o0;
+    if (col == 0) count[b] = (double)cnt;
+    if (col >= C) return;
+    const size_t o = (size_t)b * C + col;
+    if (cnt == 0) { mean[o] = 0.0; m2[o] = 0.0; return; }
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = bin_piece0[b]; k < bin_piece0[b + 1]; ++k) {
+        s1 += partials[((size_t)k * 2 + 0) * C + col];
+        s2 += partials[((size_t)k * 2 + 1) * C + col];
+    }
+    const double n = (double)cnt;
+    const double kd = (double)feats[(size_t)perm[o0] * C + col];
+    mean[o] = kd + s1 / n;
+    const double v = s2 - s1 * s1 / n;
+    m2[o] = v > 0.0 ? v : 0.0;
+}
+
+extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t* bins, int n, int C, int nb,
+                                     double* count, double* mean, double* m2,
+                                     void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!bins && n > 0, DIR_EINVAL);
+    DIR_RETURN_IF(!count || !mean || !m2 || n < 0 || C <= 0 || nb <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(!feats && n > 0, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    hipStream_t s = dir_s(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(double) * nb, s);
+        if (e == hipSuccess) e = hipMemsetAsync(mean, 0, sizeof(double) * (size_t)nb * C, s);
+        if (e == hipSuccess) e = hipMemsetAsync(m2, 0, sizeof(double) * (size_t)nb * C, s);
+        return (int)e;
+    }
+    DIR_RETURN_IF(!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
+    ScatterWs w = carve_ws(workspace, n, C, nb);
+    DIR_RETURN_IF(workspace_bytes < w.bytes, DIR_EWORKSPACE);
+    const float* f = static_cast<const float*>(feats);
+    const size_t lds_nb = sizeof(int32_t) * (size_t)nb;
+    DIR_RETURN_IF(2 * (lds_nb + 4) > 64 * 1024, DIR_EUNSUPPORTED);
+
+    hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s, bins, n, nb, w.tile_hist);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(DIR_TPB), 2 * (lds_nb + sizeof(int32_t)), s,
+                       w.tile_hist, w.ntiles, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
+                       w.piece_bin, w.piece_p0, w.piece_p1);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s,
+                       bins, n, nb, w.tile_hist, w.offsets, w.perm);
+    DIR_LAUNCH_CHECK();
+    const bool vec4 = (C % 4 == 0) && dir_aligned16(feats);
+    if (vec4) {
+        dim3 grid(w.maxpieces, dir_cdiv(C, DIR_TPB * 4));
+        hipLaunchKernelGGL(fds_piece_sums_kernel<4>, grid, dim3(DIR_TPB), 0, s, f, C, w.perm, w.offsets,
+                           w.npieces, w.piece_bin, w.piece_p0, w.piece_p1, w.partials);
+    } else {
+        dim3 grid(w.maxpieces, dir_cdiv(C, DIR_TPB));
+        hipLaunchKernelGGL(fds_piece_sums_kernel<1>, grid, dim3(DIR_TPB), 0, s, f, C, w.perm, w.offsets,
+                           w.npieces, w.piece_bin, w.piece_p0, w.piece_p1, w.partials);
+    }
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_combine_kernel, dim3(nb, dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0, s,
+                       f, C, nb, w.perm, w.offsets, w.bin_piece0, w.partials, count, mean, m2);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// =============================================================================================
+// K3: momentum update of the running tables
+// =============================================================================================
+__global__ void __launch_bounds__(DIR_TPB)
+fds_finalize_tables_kernel(const double* __restrict__ count, const double* __restrict__ mean,
+                           const double* __restrict__ m2, int C, int factor_mode, double momentum,
+                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                           const float* __restrict__ tracked) {
+    const int b = blockIdx.x;
+    const double n = count[b];
+    if (n <= 0.0) return;                                   // bin unseen this epoch: keep (fds.py loop skips it)
+    double factor;
+    if (factor_mode == DIR_FACTOR_ZERO) factor = 0.0;
+    else if (factor_mode == DIR_FACTOR_MOMENTUM) factor = momentum;
+    else factor = 1.0 - n / (double)(tracked[b] + (float)n);    // fds.py:105-106 with the bumped counter
+    const float a = (float)(1.0 - factor), f = (float)factor;
+    for (int col = blockIdx.y * DIR_TPB + threadIdx.x; col < C; col += gridDim.y * DIR_TPB) {
+        const size_t o = (size_t)b * C + col;
+        const float cm = (float)mean[o];
+        const float cv = (n == 1.0) ? 0.0f : (float)(m2[o] / (n - 1.0));   // fds.py:102
+        running_mean[o] = a * cm + f * running_mean[o];
+        running_var[o] = a * cv + f * running_var[o];
+    }
+}
+
+__global__ void fds_finalize_tracked_kernel(const double* __restrict__ count, int nb, float* __restrict__ tracked) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb && count[b] > 0.0) tracked[b] = tracked[b] + (float)count[b];   // fds.py:104
+}
+
+extern "C" int dir_fds_finalize_update(const double* count, const double* mean, const double* m2, int nb, int C,
+                                       int factor_mode, double momentum,
+                                       float* running_mean, float* running_var, float* num_samples_tracked,
+                                       dir_stream_t stream) {
+    DIR_RETURN_IF(!count || !mean || !m2 || !running_mean || !running_var || !num_samples_tracked, DIR_EINVAL);
+    DIR_RETURN_IF(nb <= 0 || C <= 0 || factor_mode < 0 || factor_mode > 2, DIR_EINVAL);
+    int gy = dir_cdiv(C, DIR_TPB); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(fds_finalize_tables_kernel, dim3(nb, gy), dim3(DIR_TPB), 0, dir_s(stream),
+                       count, mean, m2, C, factor_mode, momentum, running_mean, running_var, num_samples_tracked);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_finalize_tracked_kernel, dim3(dir_cdiv(nb, DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream),
+                       count, nb, num_samples_tracked);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// =============================================================================================
+// K4: smoothing across bins (reflect padding), mean and var tables in one launch
+// =============================================================================================
+__device__ __forceinline__ int reflect_idx(int i, int nb) {
+    if (i < 0) i = -i;
+    if (i >= nb) i = 2 * (nb - 1) - i;
+    return i;
+}
+
+__global__ void __launch_bounds__(DIR_TPB)
+fds_smooth_bins_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                       const float* __restrict__ window, int ks, int nb, int C,
+                       float* __restrict__ smean, float* __restrict__ svar) {
+    const int b = blockIdx.x;
+    const float* __restrict__ in = blockIdx.z ? var : mean;
+    float* __restrict__ out = blockIdx.z ? svar : smean;
+    const int h = ks / 2;
+    for (int col = blockIdx.y * DIR_TPB + threadIdx.x; col < C; col += gridDim.y * DIR_TPB) {
+        float acc = 0.0f;
+        for (int k = 0; k < ks; ++k) {
+            const int r = reflect_idx(b + k - h, nb);        // block-uniform
+            acc = acc + window[k] * in[(size_t)r * C + col];
+        }
+        out[(size_t)b * C + col] = acc;
+    }
+}
+
+extern "C" int dir_fds_smooth_bins(const float* mean, const float* var, const float* window, int ks, int nb, int C,
+                                   float* smoothed_mean, float* smoothed_var, dir_stream_t stream) {
+    DIR_RETURN_IF(!mean || !var || !window || !smoothed_mean || !smoothed_var, DIR_EINVAL);
+    DIR_RETURN_IF(nb <= 0 || C <= 0 || ks <= 0 || (ks & 1) == 0 || ks / 2 >= nb, DIR_EINVAL);
+    DIR_RETURN_IF(smoothed_mean == mean || smoothed_var == var, DIR_EINVAL);
+    int gy = dir_cdiv(C, DIR_TPB); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(fds_smooth_bins_kernel, dim3(nb, gy, 2), dim3(DIR_TPB), 0, dir_s(stream),
+                       mean, var, window, ks, nb, C, smoothed_mean, smoothed_var);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// =============================================================================================
+// K5a: multiplier table
+// =============================================================================================
+__global__ void __launch_bounds__(DIR_TPB)
+fds_prepare_scale_kernel(const float* __restrict__ v1, const float* __restrict__ v2, int C,
+                         float clip_min, float clip_max, float* __restrict__ scale) {
+    __shared__ double wsum[DIR_TPB / DIR_WAVE];
+    const int b = blockIdx.x;
+    const float* r1 = v1 + (size_t)b * C;
+    const float* r2 = v2 + (size_t)b * C;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += DIR_TPB) s += (double)r1[c];
+    s = dir_wave_sum(s);
+    if ((threadIdx.x & (DIR_WAVE - 1)) == 0) wsum[threadIdx.x / DIR_WAVE] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIR_TPB / DIR_WAVE; ++i) tot += wsum[i];
+    const bool row_identity = tot < 1e-10;                  // utils.py:98-99
+    for (int c = threadIdx.x; c < C; c += DIR_TPB) {
+        const float a = r1[c];
+        float out;
+        if (row_identity || a == 0.0f) out = -1.0f;          // utils.py:100-104
+        else {
+            float q = r2[c] / a;
+            q = (q < clip_min) ? clip_min : ((q > clip_max) ? clip_max : q);   // NaN falls through
+            out = sqrtf(q);
+        }
+        scale[(size_t)b * C + c] = out;
+    }
+}
+
+extern "C" int dir_fds_prepare_scale(const float* v1, const float* v2, int nb, int C, float clip_min, float clip_max,
+                                     float* scale, dir_stream_t stream) {
+    DIR_RETURN_IF(!v1 || !v2 || !scale || nb <= 0 || C <= 0, DIR_EINVAL);
+    hipLaunchKernelGGL(fds_prepare_scale_kernel, dim3(nb), dim3(DIR_TPB), 0, dir_s(stream),
+                       v1, v2, C, clip_min, clip_max, scale);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// =============================================================================================
+// K5 / K6: calibration forward (in place) and backward; fused label->bin variant for a batch
+// =============================================================================================
+__device__ __forceinline__ float calib1(float x, float m1, float s, float m2) {
+    return (s < 0.0f) ? x : (x - m1) * s + m2;               // utils.py:107, contraction off
+}
+
+template <int VEC, bool FUSED>
+__global__ void __launch_bounds__(DIR_TPB)
+fds_calibrate_fwd_kernel(float* __restrict__ x, const int32_t* __restrict__ bins_in,
+                         const float* __restrict__ labels, int B, int C, float lo, float hi,
+                         const float* __restrict__ m1, const float* __restrict__ scale,
+                         const float* __restrict__ m2, int32_t* __restrict__ bins_out) {
+    const int row = blockIdx.x;
+    int bin;
+    if (FUSED) {
+        // every workgroup rescans the (small) label vector for the two presence flags (A.3)
+        int has = 0;
+        for (int i = threadIdx.x; i < B; i += DIR_TPB) {
+            const float l = labels[i];
+            has |= (l == lo ? 1 : 0) | (l == hi ? 2 : 0);
+        }
+        has = __syncthreads_or(has);
+        bin = dir_bin_of(labels[row], lo, hi, has & 1, has & 2);
+        if (blockIdx.y == 0 && threadIdx.x == 0) bins_out[row] = bin;
+    } else {
+        bin = bins_in[row];
+    }
+    if (bin < 0) return;
+    const size_t xo = (size_t)row * C, to = (size_t)bin * C;
+    if (VEC == 4) {
+        const int col = (blockIdx.y * DIR_TPB + threadIdx.x) * 4;
+        if (col >= C) return;
+        float4 v = *reinterpret_cast<float4*>(x + xo + col);
+        const float4 a = *reinterpret_cast<const float4*>(m1 + to + col);
+        const float4 s = *reinterpret_cast<const float4*>(scale + to + col);
+        const float4 c = *reinterpret_cast<const float4*>(m2 + to + col);
+        v.x = calib1(v.x, a.x, s.x, c.x); v.y = calib1(v.y, a.y, s.y, c.y);
+        v.z = calib1(v.z, a.z, s.z, c.z); v.w = calib1(v.w, a.w, s.w, c.w);
+        *reinterpret_cast<float4*>(x + xo + col) = v;
+    } else {
+        const int col = blockIdx.y * DIR_TPB + threadIdx.x;
+        if (col >= C) return;
+        x[xo + col] = calib1(x[xo + col], m1[to + col], scale[to + col], m2[to + col]);
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(DIR_TPB)
+fds_calibrate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                         const int32_t* __restrict__ bins, int C, const float* __restrict__ scale) {
+    const int row = blockIdx.x;
+    const int bin = bins[row];
+    const size_t xo = (size_t)row * C, to = (size_t)(bin < 0 ? 0 : bin) * C;
+    if (VEC == 4) {
+        const int col = (blockIdx.y * DIR_TPB + threadIdx.x) * 4;
+        if (col >= C) return;
+        float4 g = *reinterpret_cast<const float4*>(dy + xo + col);
+        if (bin >= 0) {
+            const float4 s = *reinterpret_cast<const float4*>(scale + to + col);
+            g.x = s.x < 0.0f ? g.x : g.x * s.x; g.y = s.y < 0.0f ? g.y : g.y * s.y;
+            g.z = s.z < 0.0f ? g.z : g.z * s.z; g.w = s.w < 0.0f ? g.w : g.w * s.w;
+        }
+        *reinterpret_cast<float4*>(dx + xo + col) = g;
+    } else {
+        const int col = blockIdx.y * DIR_TPB + threadIdx.x;
+        if (col >= C) return;
+        float g = dy[xo + col];
+        if (bin >= 0) { const float s = scale[to + col]; g = s < 0.0f ? g : g * s; }
+        dx[xo + col] = g;
+    }
+}
+
+static bool vec4_ok(int C, const void* a, const void* b, const void* c, const void* d) {
+    return (C % 4 == 0) && dir_aligned16(a) && dir_aligned16(b) && dir_aligned16(c) && dir_aligned16(d);
+}
+
+extern "C" int dir_fds_calibrate_fwd(void* x_inout, int dtype, const int32_t* bins, int B, int C,
+                                     const float* m1, const float* scale, const float* m2, dir_stream_t stream) {
+    DIR_RETURN_IF(B < 0 || C <= 0, DIR_EINVAL);
+    if (B == 0) return DIR_OK;
+    DIR_RETURN_IF(!x_inout || !bins || !m1 || !scale || !m2, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    float* x = static_cast<float*>(x_inout);
+    if (vec4_ok(C, x, m1, scale, m2)) {
+        hipLaunchKernelGGL((fds_calibrate_fwd_kernel<4, false>), dim3(B, dir_cdiv(C, DIR_TPB * 4)), dim3(DIR_TPB), 0,
+                           dir_s(stream), x, bins, nullptr, B, C, 0.f, 0.f, m1, scale, m2, nullptr);
+    } else {
+        hipLaunchKernelGGL((fds_calibrate_fwd_kernel<1, false>), dim3(B, dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0,
+                           dir_s(stream), x, bins, nullptr, B, C, 0.f, 0.f, m1, scale, m2, nullptr);
+    }
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_fds_calibrate_bwd(const void* dy, void* dx, int dtype, const int32_t* bins, int B, int C,
+                                     const float* scale, dir_stream_t stream) {
+    DIR_RETURN_IF(B < 0 || C <= 0, DIR_EINVAL);
+    if (B == 0) return DIR_OK;
+    DIR_RETURN_IF(!dy || !dx || !bins || !scale, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    const float* g = static_cast<const float*>(dy);
+    float* o = static_cast<float*>(dx);
+    if (vec4_ok(C, g, o, scale, scale)) {
+        hipLaunchKernelGGL(fds_calibrate_bwd_kernel<4>, dim3(B, dir_cdiv(C, DIR_TPB * 4)), dim3(DIR_TPB), 0,
+                           dir_s(stream), g, o, bins, C, scale);
+    } else {
+        hipLaunchKernelGGL(fds_calibrate_bwd_kernel<1>, dim3(B, dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0,
+                           dir_s(stream), g, o, bins, C, scale);
+    }
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+#define SMOOTH_FUSED_MAX_B 2048
+
+extern "C" int dir_fds_smooth_fwd(void* x_inout, int dtype, const float* labels, int B, int C,
+                                  int bucket_start, int bucket_num,
+                                  const float* m1, const float* scale, const float* m2,
+                                  int32_t* bins_out, dir_stream_t stream) {
+    DIR_RETURN_IF(B < 0 || C <= 0, DIR_EINVAL);
+    if (B == 0) return DIR_OK;
+    DIR_RETURN_IF(!x_inout || !labels || !m1 || !scale || !m2 || !bins_out, DIR_EINVAL);
+    DIR_RETURN_IF(check_buckets(bucket_start, bucket_num), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    float* x = static_cast<float*>(x_inout);
+    const float lo = (float)bucket_start, hi = (float)(bucket_num - 1);
+    if (B > SMOOTH_FUSED_MAX_B) {
+        // large batches: a per-workgroup rescan of the labels would be O(B^2) -> K1 then K5.
+        // bins_out has B + 1 slots by contract; the extra one holds the presence-flag word.
+        uint32_t* flags = reinterpret_cast<uint32_t*>(bins_out + B);
+        int rc = dir_fds_bin_index(labels, B, bucket_start, bucket_num, bins_out, flags, stream);
+        if (rc) return rc;
+        return dir_fds_calibrate_fwd(x_inout, dtype, bins_out, B, C, m1, scale, m2, stream);
+    }
+    if (vec4_ok(C, x, m1, scale, m2)) {
+        hipLaunchKernelGGL((fds_calibrate_fwd_kernel<4, true>), dim3(B, dir_cdiv(C, DIR_TPB * 4)), dim3(DIR_TPB), 0,
+                           dir_s(stream), x, nullptr, labels, B, C, lo, hi, m1, scale, m2, bins_out);
+    } else {
+        hipLaunchKernelGGL((fds_calibrate_fwd_kernel<1, true>), dim3(B, dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0,
+                           dir_s(stream), x, nullptr, labels, B, C, lo, hi, m1, scale, m2, bins_out);
+    }
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

@@ -1,0 +1,103 @@
+"""ctypes binding of ``libdir_hip.so`` (C-ABI declared in ``include/dir_hip.h``).
+
+There is exactly one compute path: the hand-written gfx950 kernels in this library. If the
+library is missing or an entry point fails, the caller gets an exception — there is no eager /
+CPU fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdir_hip.so")
+
+c_int, c_float, c_double, c_void_p, c_size_t, c_int64 = (
+    ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64)
+
+# name -> (restype, argtypes); must list every symbol of include/dir_hip.h
+SIGNATURES = {
+    "dir_abi_version": (c_int, []),
+    "dir_error_string": (ctypes.c_char_p, [c_int]),
+    "dir_fds_label_flags": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dir_fds_assign_bins": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_bin_index": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_scatter_stats_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "dir_fds_scatter_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_fds_finalize_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_smooth_bins": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_prepare_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "dir_fds_calibrate_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_calibrate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dir_fds_smooth_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "dir_weighted_loss_workspace": (c_size_t, [c_int]),
+    "dir_weighted_loss": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+}
+
+DIR_F32, DIR_BF16 = 0, 1
+FLAG_HAS_LO, FLAG_HAS_HI, FLAG_NONINTEGER, FLAG_NAN = 1, 2, 4, 8
+FACTOR_ZERO, FACTOR_MOMENTUM, FACTOR_COUNT = 0, 1, 2
+LOSS_KINDS = {"mse": 0, "l1": 1, "focal_mse": 2, "focal_l1": 3, "huber": 4}
+REWEIGHT = {"sqrt_inv": 1, "inverse": 2}
+
+_lib = None
+
+
+class DirHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once). Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise DirHipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                f"(or `make -C imbalanced-regression_amd/csrc`). There is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError = ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dir_abi_version() != 1:
+            raise DirHipError(f"ABI version mismatch: {handle.dir_abi_version()}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dir_error_string(rc).decode()
+        if rc > 0:
+            msg += f" [hipError_t {rc}]"
+        raise DirHipError(f"{what} failed: {msg}")
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream (kernels are enqueued where torch's work is)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_device_tensor(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise DirHipError(
+            f"{name} is on {t.device}: the FDS/LDS hot path runs only as HIP kernels on an AMD GPU "
+            f"(no CPU fallback). Move the tensor to the GPU.")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t

@@ -1,0 +1,128 @@
+"""ResNet-50 age regressor — drop-in for ``imdb-wiki-dir/resnet.py`` (= ``agedb-dir/resnet.py``).
+
+Same constructor keywords (``resnet50(fds=, bucket_num=, bucket_start=, start_update=, start_smooth=,
+kernel=, ks=, sigma=, momentum=[, dropout=])``), same sub-module names (-> state_dict keys, so
+reference checkpoints load), same initialisation stream, same forward contract
+(``(pred, encoding)`` when training with FDS, else ``pred``; the returned ``encoding`` is the tensor
+``FDS.smooth`` calibrated in place — SURVEY A.2).
+
+Round-1 backbone: the conv/BN/ReLU stack is expressed with torch.nn modules (MIOpen / hipBLASLt
+MFMA implicit-GEMM under bf16 autocast + channels_last, driven by ``dirhip.engine``); the
+pool -> FDS calibrate -> linear -> weighted-loss tail is the hand-written HIP path and always fp32.
+"""
+import logging
+import math
+
+import torch
+import torch.nn as nn
+
+from .fds import FDS
+
+print = logging.info
+
+
+class Bottleneck(nn.Module):
+    """1x1 reduce -> 3x3 (carries the stride) -> 1x1 expand, BN after each, residual add (resnet.py:41-70)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        width_out = planes * self.expansion
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, width_out, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width_out)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        y += shortcut
+        return self.relu(y)
+
+
+class ResNet(nn.Module):
+
+    def __init__(self, block, layers, fds, bucket_num, bucket_start, start_update, start_smooth,
+                 kernel, ks, sigma, momentum, dropout=None):
+        self.inplanes = 64
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+        self.linear = nn.Linear(512 * block.expansion, 1)
+
+        if fds:
+            self.FDS = FDS(feature_dim=512 * block.expansion, bucket_num=bucket_num, bucket_start=bucket_start,
+                           start_update=start_update, start_smooth=start_smooth, kernel=kernel, ks=ks,
+                           sigma=sigma, momentum=momentum)
+        self.fds = fds
+        self.start_smooth = start_smooth
+
+        self.use_dropout = True if dropout else False
+        if self.use_dropout:
+            print(f'Using dropout: {dropout}')
+            self.dropout = nn.Dropout(p=dropout)
+
+        # resnet.py:103-109: He-normal on fan-out for every conv, BN gamma 1 / beta 0
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / fan_out))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion),
+            )
+        stages = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        stages += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stages)
+
+    def features(self, x):
+        """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        return x.view(x.size(0), -1)
+
+    def forward(self, x, targets=None, epoch=None):
+        encoding = self.features(x)
+        # the FDS / linear / loss tail is fp32 whatever precision the conv stack ran in
+        with torch.autocast(device_type=encoding.device.type, enabled=False):
+            if encoding.dtype != torch.float32:
+                encoding = encoding.float()
+            encoding_s = encoding
+            if self.training and self.fds:
+                if epoch >= self.start_smooth:
+                    encoding_s = self.FDS.smooth(encoding_s, targets, epoch)     # in place (A.2)
+            if self.use_dropout:
+                encoding_s = self.dropout(encoding_s)
+            x = self.linear(encoding_s)
+
+        if self.training and self.fds:
+            return x, encoding
+        else:
+            return x
+
+
+def resnet50(**kwargs):
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)

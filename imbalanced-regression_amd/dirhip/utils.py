@@ -1,0 +1,140 @@
+"""Drop-in for ``imdb-wiki-dir/utils.py`` (= ``agedb-dir/utils.py``).
+
+Kernel-backed: ``calibrate_mean_var`` (utils.py:97-107). Host, bit-exact: ``get_lds_kernel_window``
+(utils.py:110-122; scipy on the host like the reference). The remaining helpers
+(``AverageMeter`` ... ``save_checkpoint``) are plain host utilities ``train.py`` star-imports, together with
+the names ``torch`` / ``np`` / ``os`` / ``logging`` / ``shutil`` it relies on.
+"""
+import os
+import shutil
+import torch
+import logging
+import numpy as np
+from scipy.ndimage import gaussian_filter1d
+from scipy.signal.windows import triang
+
+from . import _lib as L
+from . import ops
+
+
+class AverageMeter(object):
+    """Running value / average of one scalar (utils.py:10-30)."""
+
+    def __init__(self, name, fmt=':f'):
+        self.name, self.fmt = name, fmt
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return ('{name} {val' + self.fmt + '} ({avg' + self.fmt + '})').format(**self.__dict__)
+
+
+class ProgressMeter(object):
+    """utils.py:33-48."""
+
+    def __init__(self, num_batches, meters, prefix=""):
+        width = len(str(num_batches // 1))
+        self.batch_fmtstr = '[{:' + str(width) + 'd}/' + ('{:' + str(width) + 'd}').format(num_batches) + ']'
+        self.meters = meters
+        self.prefix = prefix
+
+    def display(self, batch):
+        logging.info('\t'.join([self.prefix + self.batch_fmtstr.format(batch)] + [str(m) for m in self.meters]))
+
+
+def query_yes_no(question):
+    """utils.py:51-64. Non-interactive sessions (no tty) answer yes instead of blocking on input()."""
+    import sys
+    if not sys.stdin or not sys.stdin.isatty():
+        return True
+    answers = {"yes": True, "y": True, "ye": True, "no": False, "n": False}
+    while True:
+        print(question + " [Y/n] ", end=':')
+        choice = input().lower()
+        if choice == '':
+            return True
+        if choice in answers:
+            return answers[choice]
+        print("Please respond with 'yes' or 'no' (or 'y' or 'n').\n")
+
+
+def prepare_folders(args):
+    """utils.py:67-78."""
+    store = os.path.join(args.store_root, args.store_name)
+    if os.path.exists(store) and not args.resume and not args.pretrained and not args.evaluate:
+        if query_yes_no('overwrite previous folder: {} ?'.format(store)):
+            shutil.rmtree(store)
+            print(store + ' removed.')
+        else:
+            raise RuntimeError('Output folder {} already exists'.format(store))
+    for folder in (args.store_root, store):
+        if not os.path.exists(folder):
+            print(f"===> Creating folder: {folder}")
+            os.makedirs(folder, exist_ok=True)
+
+
+def adjust_learning_rate(optimizer, epoch, args):
+    """utils.py:81-86: step schedule, x0.1 at every milestone reached."""
+    lr = args.lr
+    for milestone in args.schedule:
+        lr *= 0.1 if epoch >= milestone else 1.
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+
+
+def save_checkpoint(args, state, is_best, prefix=''):
+    """utils.py:89-94: <store_root>/<store_name>/ckpt.pth.tar (+ ckpt.best.pth.tar)."""
+    filename = f"{args.store_root}/{args.store_name}/{prefix}ckpt.pth.tar"
+    torch.save(state, filename)
+    if is_best:
+        logging.info("===> Saving current best checkpoint...")
+        shutil.copyfile(filename, filename.replace('pth.tar', 'best.pth.tar'))
+
+
+class _CalibrateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, matrix, m1, v1, m2, v2, clip_min, clip_max):
+        c = matrix.shape[1]
+        scale = ops.prepare_scale(v1.reshape(1, c).contiguous(), v2.reshape(1, c).contiguous(), clip_min, clip_max)
+        bins = torch.zeros(matrix.shape[0], dtype=torch.int32, device=matrix.device)
+        out = matrix.clone(memory_format=torch.contiguous_format)
+        ops.calibrate_fwd_(out, bins, m1.reshape(1, c).contiguous(), scale, m2.reshape(1, c).contiguous())
+        ctx.save_for_backward(bins, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        bins, scale = ctx.saved_tensors
+        return ops.calibrate_bwd(grad_out, bins, scale), None, None, None, None, None, None
+
+
+def calibrate_mean_var(matrix, m1, v1, m2, v2, clip_min=0.1, clip_max=10):
+    """utils.py:97-107 on the GPU: ``(matrix - m1) * sqrt(clamp(v2 / v1)) + m2`` for the columns with
+    ``v1 != 0``, the input unchanged when ``sum(v1) < 1e-10``. matrix [n, C]; m1, v1, m2, v2 [C].
+    Always returns a new tensor (the reference returns the input object itself on two of its three branches)."""
+    for t, nm in ((matrix, "matrix"), (m1, "m1"), (v1, "v1"), (m2, "m2"), (v2, "v2")):
+        L.require_device_tensor(t if t.is_contiguous() else t.contiguous(), torch.float32, nm)
+    assert matrix.dim() == 2
+    return _CalibrateFn.apply(matrix, m1, v1, m2, v2, float(clip_min), float(clip_max))
+
+
+def get_lds_kernel_window(kernel, ks, sigma):
+    """utils.py:110-122: float64 numpy window; gaussian / laplace divided by their MAX, triang as is."""
+    assert kernel in ['gaussian', 'triang', 'laplace']
+    half_ks = (ks - 1) // 2
+    if kernel == 'gaussian':
+        delta = [0.] * half_ks + [1.] + [0.] * half_ks
+        smoothed = gaussian_filter1d(delta, sigma=sigma)
+        return smoothed / max(smoothed)
+    if kernel == 'triang':
+        return triang(ks)
+    taps = [np.exp(-abs(x) / sigma) / (2. * sigma) for x in np.arange(-half_ks, half_ks + 1)]
+    return np.asarray(taps) / max(taps)

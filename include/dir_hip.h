@@ -1,0 +1,186 @@
+/* dir_hip.h — C-ABI of libdir_hip.so: MI355X (gfx950) kernels for the LDS/FDS hot path of
+ * YyzHarry/imbalanced-regression (imdb-wiki-dir / agedb-dir).
+ *
+ * The reference has no FFI (it is 100 % Python); its boundary is the Python module
+ * surface fds.py / loss.py / utils.py / datasets.py. Each entry point below names the reference
+ * lines whose device work it replaces. Conventions:
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller unless the comment says "host";
+ *     nothing is allocated inside; scratch comes from a caller-provided workspace.
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no host synchronisation inside; re-entrant (no global state).
+ *   - return 0 on success, DIR_E* (< 0) for argument errors, hipError_t (> 0) for runtime errors.
+ *   - row-major contiguous arrays; "f32" = IEEE float32, "f64" = IEEE float64.
+ *   - kernels are compiled with -ffp-contract=off: every float32 expression below is evaluated
+ *     exactly as written (one rounding per operation), like the reference's eager torch ops.
+ */
+#ifndef DIR_HIP_H
+#define DIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIR_ABI_VERSION 1
+
+#define DIR_OK            0
+#define DIR_EINVAL       (-1)   /* bad argument (null pointer, non-positive size, ks even, ...) */
+#define DIR_EUNSUPPORTED (-2)   /* valid request this build does not implement (dtype, mode)    */
+#define DIR_EWORKSPACE   (-3)   /* workspace too small                                          */
+
+/* feature dtypes */
+#define DIR_F32  0
+#define DIR_BF16 1
+
+/* label-scan flag bits written by dir_fds_label_flags */
+#define DIR_FLAG_HAS_LO      1u  /* some label == bucket_start        (fds.py:94, :123)          */
+#define DIR_FLAG_HAS_HI      2u  /* some label == bucket_num - 1      (fds.py:96, :130)          */
+#define DIR_FLAG_NONINTEGER  4u  /* an in-range label with a fractional part        */
+#define DIR_FLAG_NAN         8u  /* a NaN label                                                   */
+
+typedef void* dir_stream_t;      /* hipStream_t */
+
+int         dir_abi_version(void);
+const char* dir_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  label -> table row ("bin").  Replaces the host loop `for label in torch.unique(labels)` and
+ * its per-label branch (imdb-wiki-dir/fds.py:91-99 and :120-137):
+ *   l > num-1  -> rows used only if some label == num-1 in this call (then bin = num-1-start)
+ *   l < start  -> rows used only if some label == start in this call (then bin = 0)
+ *   otherwise  -> bin = (int)(l - start)      (float32 subtraction, truncation; fds.py:104)
+ *   bin = -1   -> row untouched / not counted.
+ * The presence flags are a separate step so that a data-parallel caller can OR-reduce them across
+ * ranks between the two calls.  flags: one uint32 on the device, OR-ed into (the
+ * caller zeroes it, or calls dir_fds_bin_index which does).
+ */
+int dir_fds_label_flags(const float* labels, int n, int bucket_start, int bucket_num,
+                        uint32_t* flags, dir_stream_t stream);
+int dir_fds_assign_bins(const float* labels, int n, int bucket_start, int bucket_num,
+                        const uint32_t* flags, int32_t* bins, dir_stream_t stream);
+/* both steps, single rank; zeroes *flags first */
+int dir_fds_bin_index(const float* labels, int n, int bucket_start, int bucket_num,
+                      int32_t* bins, uint32_t* flags, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  per-bin sufficient statistics of the feature matrix.  Replaces, for every label, the boolean
+ * mask + gather copy + torch.mean + torch.var of imdb-wiki-dir/fds.py:95-102.
+ *   feats [n, C] (dtype), bins [n] int32 from K1 (-1 rows are skipped).
+ *   out: count [nb] f64 (exact integers), mean [nb, C] f64, m2 [nb, C] f64 where
+ *        m2 = sum_rows (x - mean)^2   (so var_unbiased = m2 / (count - 1)); bins with no rows get
+ *        count = 0, mean = 0, m2 = 0.
+ * One streaming pass over feats: rows are grouped by bin with a stable counting sort, every
+ * (bin, <=rows_per_piece rows) piece is reduced in registers in float64 around a per-bin shift
+ * (the bin's first row, so a constant column has m2 == 0 exactly, like torch.var — SURVEY A.7/A.9),
+ * pieces are combined in a fixed order: results are bit-reproducible run to run.
+ * (count, mean, m2) triples from several ranks merge with Chan's formula.
+ * workspace: >= dir_fds_scatter_stats_workspace(n, C, nb) bytes, 256-byte aligned.
+ */
+size_t dir_fds_scatter_stats_workspace(int n, int C, int nb);
+int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t* bins, int n, int C, int nb,
+                          double* count, double* mean, double* m2,
+                          void* workspace, size_t workspace_bytes, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  momentum update of the running tables.  Replaces imdb-wiki-dir/fds.py:101-111 for all bins
+ * at once.  For every bin with count > 0:
+ *   curr_mean = (f32) mean;  curr_var = count == 1 ? 0 : (f32)(m2 / (count - 1))      (fds.py:101-102)
+ *   tracked  += (f32) count                                                           (fds.py:104)
+ *   factor    = mode 0: 0 (epoch == start_update, fds.py:107)
+ *               mode 1: momentum                                                      (fds.py:105)
+ *               mode 2: 1 - count / tracked   (momentum is None, fds.py:105-106; float64)
+ *   running   = (f32)(1 - factor) * curr + (f32)factor * running                      (fds.py:108-111)
+ * Bins with count == 0 keep their values.  In place on running_mean / running_var [nb, C] f32 and
+ * num_samples_tracked [nb] f32.
+ */
+#define DIR_FACTOR_ZERO      0
+#define DIR_FACTOR_MOMENTUM  1
+#define DIR_FACTOR_COUNT     2
+int dir_fds_finalize_update(const double* count, const double* mean, const double* m2, int nb, int C,
+                            int factor_mode, double momentum,
+                            float* running_mean, float* running_var, float* num_samples_tracked,
+                            dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  smoothing across the bin axis.  Replaces the two F.pad(reflect) + F.conv1d calls of
+ * imdb-wiki-dir/fds.py:58-67:  out[b, c] = sum_k window[k] * in[reflect(b + k - ks/2), c],
+ * float32, taps accumulated k = 0..ks-1, for the mean and the var table in one launch.
+ * window [ks] f32 on the device; ks odd, ks/2 < nb.  Outputs are contiguous [nb, C].
+ */
+int dir_fds_smooth_bins(const float* mean, const float* var, const float* window, int ks, int nb, int C,
+                        float* smoothed_mean, float* smoothed_var, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5a calibration multiplier table.  Replaces the per-call recomputation of
+ * torch.sqrt(torch.clamp(v2 / v1, clip_min, clip_max)) and the two guards of
+ * imdb-wiki-dir/utils.py:98-104, once per table change instead of once per label per step:
+ *   scale[b, c] = -1                        if sum_c v1[b, :] < 1e-10      (utils.py:98-99)
+ *               = -1                        if v1[b, c] == 0               (utils.py:100-104)
+ *               = sqrtf(clamp(v2/v1))       otherwise (NaN propagates)     (utils.py:106-107)
+ * -1 means "leave the element untouched" (a real multiplier is never negative).
+ */
+int dir_fds_prepare_scale(const float* v1, const float* v2, int nb, int C, float clip_min, float clip_max,
+                          float* scale, dir_stream_t stream);
+
+/* K5  calibration, forward, IN PLACE.  Replaces the per-label
+ * `features[mask] = calibrate_mean_var(features[mask], m1[b], v1[b], m2[b], v2[b])` of
+ * imdb-wiki-dir/fds.py:120-143 + utils.py:97-107 (11 076 aten dispatches / 919 host syncs at B=256):
+ *   x[r, c] = scale[b, c] < 0 ? x[r, c] : (x[r, c] - m1[b, c]) * scale[b, c] + m2[b, c],  b = bins[r] >= 0.
+ */
+int dir_fds_calibrate_fwd(void* x_inout, int dtype, const int32_t* bins, int B, int C,
+                          const float* m1, const float* scale, const float* m2, dir_stream_t stream);
+/* K6  its autograd:  dx[r, c] = (bins[r] < 0 || scale < 0) ? dy : dy * scale.  dx may alias dy. */
+int dir_fds_calibrate_bwd(const void* dy, void* dx, int dtype, const int32_t* bins, int B, int C,
+                          const float* scale, dir_stream_t stream);
+/* K1+K5 in one launch for a training batch (FDS.smooth, fds.py:115-144): labels [B] f32;
+ * bins_out [B + 1] int32: the first B entries receive the bins for the backward, the last one is
+ * scratch.  Any B (falls back to K1 then K5 above a batch-size threshold). */
+int dir_fds_smooth_fwd(void* x_inout, int dtype, const float* labels, int B, int C,
+                       int bucket_start, int bucket_num,
+                       const float* m1, const float* scale, const float* m2,
+                       int32_t* bins_out, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  weighted regression losses, forward + gradient in one launch.  Replaces
+ * imdb-wiki-dir/loss.py:5-48 (weighted_{mse,l1,focal_mse,focal_l1,huber}_loss) and their autograd.
+ *   x, y, w [n] f32 (w may be NULL = unweighted);  loss[0] = mean_i(per_i * w_i)  f32;
+ *   dx_unit [n] = d loss / d x_i for an upstream gradient of 1 (may be NULL).
+ *   beta:  focal: loss.py default .2 ; huber: loss.py default 1.   gamma: focal exponent.
+ *   activate: 0 = sigmoid (default), 1 = tanh.
+ * workspace: >= dir_weighted_loss_workspace(n) bytes (may be NULL when that is 0).
+ */
+#define DIR_LOSS_MSE        0
+#define DIR_LOSS_L1         1
+#define DIR_LOSS_FOCAL_MSE  2
+#define DIR_LOSS_FOCAL_L1   3
+#define DIR_LOSS_HUBER      4
+size_t dir_weighted_loss_workspace(int n);
+int dir_weighted_loss(int kind, const float* x, const float* y, const float* w, int n,
+                      float beta, float gamma, int activate,
+                      float* loss, float* dx_unit, void* workspace, size_t workspace_bytes,
+                      dir_stream_t stream);
+/* out[i] = in[i] * scalar[0]  (scalar on the device: the upstream gradient of the loss) */
+int dir_scale_by_device_scalar(const float* in, const float* scalar, float* out, int n, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  LDS per-sample weights — HOST function, all pointers are host pointers.  Replaces
+ * imdb-wiki-dir/datasets.py:55-83 (_prepare_weights), bit for bit:
+ *   bin = min(max_target-1, (int)label); counts -> sqrt (f64) | clip(5,1000) (int64);
+ *   if lds: scipy.ndimage.convolve1d(mode='constant') with `window` [ks] f64
+ *           (symmetric-kernel accumulation order, integer counts stay integer — SURVEY A.5/E.1);
+ *   w_i = (f32)(1 / value[bin_i]); scaling = (f32)n / pairwise_f32_sum(w) (numpy order, E.2);
+ *   weights[i] = scaling * w_i.
+ * reweight: 1 = sqrt_inv, 2 = inverse.  window may be NULL when lds == 0.
+ */
+#define DIR_REWEIGHT_SQRT_INV 1
+#define DIR_REWEIGHT_INVERSE  2
+int dir_lds_weights(const double* labels, int64_t n, int max_target, int reweight, int lds,
+                    const double* window, int ks, float* weights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIR_HIP_H */

@@ -244,15 +244,15 @@ def gen_resnet():
     g = torch.Generator().manual_seed(99)
     x = torch.randn(2, 3, 224, 224, generator=g)
     t = torch.tensor([[31.0], [64.0]])
-    model.train()
-    with torch.no_grad(), refshim.cuda_identity():
-        pred, enc = model(x, t, 0)
-    model.eval()
-    with torch.no_grad():
-        pred_eval = model(x)
     sd = model.state_dict()
     keys = list(sd.keys())
-    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    sums = np.array([float(v.double().sum()) for v in sd.values()])       # right after construction
+    model.eval()
+    with torch.no_grad():
+        pred_eval = model(x)                                               # fresh BN running stats
+    model.train()
+    with torch.no_grad(), refshim.cuda_identity():
+        pred, enc = model(x, t, 0)                                         # batch statistics; epoch 0 -> no smoothing
     save("resnet50_forward.npz", ref_pred_train=pred.numpy(), ref_enc_train=enc.numpy(),
          ref_pred_eval=pred_eval.numpy(), keys=np.array(keys), ref_param_sums=sums,
          shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]),
