@@ -40,6 +40,12 @@ FLOP_FWD = 8.174e9
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, MI355X_MICROARCH.md (achievable ~6300)
 N_TRAIN = 191509              # IMDB-WIKI-DIR train-set size (paper; the csv is not vendored)
+_T0 = time.time()
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 def long_tail_labels(rng, n):
@@ -176,7 +182,7 @@ def cpu_baseline(seconds_budget=25.0):
     """The oracle port (torch-CPU restatement of the reference loop) on the host cores: ResNet-50 + FDS + LDS
     weights + l1 + Adam, B=8 (BASELINE configs[0] batch), epoch tail included every 4 steps."""
     from oracle import torch_oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, int(os.environ.get("DIR_CPU_BASELINE_THREADS", "64")))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = torch_oracle.RefResNet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
@@ -237,10 +243,14 @@ def main():
     store = EpochFeatures(args.epoch_len * args.batch, 2048, device)
     loss_fn = resolve_loss("l1")
 
+    log("model + data built")
     _, epoch = run_steps(engine, optimizer, batches, store, args.warmup, args.epoch_len, 2, loss_fn)
+    torch.cuda.synchronize(device)
+    log("warmup done")
     dt, (loss, epoch) = timed(lambda: run_steps(engine, optimizer, batches, store, args.steps, args.epoch_len, epoch, loss_fn),
                               device, world)
     loss_val = float(loss.item())
+    log(f"timed region done: {dt:.2f}s for {args.steps} steps")
     assert np.isfinite(loss_val) and loss_val < 1e6, f"Loss explosion: {loss_val}"
     # same steps without the tail (for the plain-ResNet comparison and the MFMA fraction of the step itself)
     dt_train, _ = timed(lambda: run_steps(engine, optimizer, batches, store, args.steps, args.epoch_len, epoch, loss_fn, with_tail=False),
@@ -269,8 +279,10 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_kernel_rooflines:
             result["kernel_rooflines"] = kernel_rooflines(device)
+            log("kernel rooflines done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline done")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

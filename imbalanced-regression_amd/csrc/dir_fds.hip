@@ -475,13 +475,14 @@ fds_calibrate_fwd_kernel(float* __restrict__ x, const int32_t* __restrict__ bins
     int bin;
     if (FUSED) {
         // every workgroup rescans the (small) label vector for the two presence flags (A.3)
-        int has = 0;
+        int has_lo = 0, has_hi = 0;
         for (int i = threadIdx.x; i < B; i += DIR_TPB) {
             const float l = labels[i];
-            has |= (l == lo ? 1 : 0) | (l == hi ? 2 : 0);
+            has_lo |= (l == lo); has_hi |= (l == hi);
         }
-        has = __syncthreads_or(has);
-        bin = dir_bin_of(labels[row], lo, hi, has & 1, has & 2);
+        has_lo = __syncthreads_or(has_lo);                  // predicate OR (returns a boolean, not a bit-OR)
+        has_hi = __syncthreads_or(has_hi);
+        bin = dir_bin_of(labels[row], lo, hi, has_lo != 0, has_hi != 0);
         if (blockIdx.y == 0 && threadIdx.x == 0) bins_out[row] = bin;
     } else {
         bin = bins_in[row];
