@@ -1,0 +1,108 @@
+"""Datasets — drop-in for ``imdb-wiki-dir/datasets.py`` / ``agedb-dir/datasets.py`` (``IMDBWIKI`` / ``AgeDB``).
+
+Same constructor and ``__getitem__ -> (img f32[3,S,S], label f32[1], weight f32[1])`` contract; ``.weights`` comes
+from the native LDS routine (``dirhip.lds.prepare_weights`` -> ``dir_lds_weights``, bit-exact with the reference's
+numpy/scipy arithmetic). Image decoding/augmentation is host-side PIL + numpy (the reference uses torchvision
+transforms, which this image does not ship): Resize -> RandomCrop(pad 16) -> RandomHorizontalFlip -> [0,1] ->
+Normalize(.5, .5) (datasets.py:38-53). ``SyntheticAgeDataset`` produces device-resident random batches with the
+same label/weight semantics for benchmarking without image files.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+from torch.utils import data
+
+from .lds import prepare_weights
+
+print = logging.info
+
+
+class _AgeDataset(data.Dataset):
+    def __init__(self, df, data_dir, img_size, split='train', reweight='none',
+                 lds=False, lds_kernel='gaussian', lds_ks=5, lds_sigma=2):
+        self.df = df
+        self.data_dir = data_dir
+        self.img_size = img_size
+        self.split = split
+        self.weights = self._prepare_weights(reweight=reweight, lds=lds, lds_kernel=lds_kernel, lds_ks=lds_ks,
+                                             lds_sigma=lds_sigma)
+
+    def __len__(self):
+        return len(self.df)
+
+    def _prepare_weights(self, reweight, max_target=121, lds=False, lds_kernel='gaussian', lds_ks=5, lds_sigma=2):
+        return prepare_weights(self.df['age'].values, reweight, max_target=max_target, lds=lds,
+                               lds_kernel=lds_kernel, lds_ks=lds_ks, lds_sigma=lds_sigma)
+
+    def get_transform(self):
+        size, train = self.img_size, self.split == 'train'
+
+        def transform(img):
+            from PIL import Image
+            img = img.resize((size, size), Image.BILINEAR)
+            arr = np.asarray(img, dtype=np.uint8)
+            if train:
+                arr = np.pad(arr, ((16, 16), (16, 16), (0, 0)))                 # RandomCrop(size, padding=16)
+                top, left = np.random.randint(0, 33), np.random.randint(0, 33)
+                arr = arr[top:top + size, left:left + size]
+                if np.random.rand() < 0.5:                                       # RandomHorizontalFlip
+                    arr = arr[:, ::-1]
+            out = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div_(255.)
+            return out.sub_(0.5).div_(0.5)                                       # Normalize([.5]*3, [.5]*3)
+        return transform
+
+    def __getitem__(self, index):
+        from PIL import Image
+        index = index % len(self.df)
+        row = self.df.iloc[index]
+        img = Image.open(os.path.join(self.data_dir, row['path'])).convert('RGB')
+        img = self.get_transform()(img)
+        label = np.asarray([row['age']]).astype('float32')
+        weight = np.asarray([self.weights[index]]).astype('float32') if self.weights is not None else \
+            np.asarray([np.float32(1.)])
+        return img, label, weight
+
+
+class IMDBWIKI(_AgeDataset):
+    pass
+
+
+class AgeDB(_AgeDataset):
+    pass
+
+
+class SyntheticAgeDataset(data.Dataset):
+    """Random 224x224 'images' with a given label list; weights from the same LDS routine. Indexable like the
+    real datasets (CPU tensors), and ``device_batches`` yields whole batches generated directly in HBM."""
+
+    def __init__(self, labels, img_size=224, reweight='none', lds=False, lds_kernel='gaussian', lds_ks=5,
+                 lds_sigma=2, seed=0):
+        self.labels = np.asarray(labels, dtype=np.float32)
+        self.img_size = img_size
+        self.seed = seed
+        self.weights = prepare_weights(self.labels, reweight, lds=lds, lds_kernel=lds_kernel, lds_ks=lds_ks,
+                                       lds_sigma=lds_sigma)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + int(index))
+        img = torch.randn(3, self.img_size, self.img_size, generator=g)
+        w = np.float32(1.) if self.weights is None else self.weights[index]
+        return img, np.asarray([self.labels[index]], dtype=np.float32), np.asarray([w], dtype=np.float32)
+
+    def device_batches(self, indices, batch_size, device, channels_last=True, seed=0):
+        w_all = None if self.weights is None else torch.as_tensor(np.asarray(self.weights, dtype=np.float32))
+        lab_all = torch.as_tensor(self.labels)
+        g = torch.Generator(device=device).manual_seed(self.seed * 7919 + seed)
+        for s in range(0, len(indices), batch_size):
+            idx = indices[s:s + batch_size]
+            x = torch.randn(len(idx), 3, self.img_size, self.img_size, device=device, generator=g)
+            if channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            y = lab_all[idx].to(device).view(-1, 1)
+            w = torch.ones_like(y) if w_all is None else w_all[idx].to(device).view(-1, 1)
+            yield x, y, w
