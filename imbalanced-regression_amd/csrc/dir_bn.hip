@@ -1,0 +1,480 @@
+// Fused BatchNorm (+ residual add) (+ ReLU) for NHWC activations on MI355X / gfx950 — forward and backward.
+//
+// Replaces, per BN layer of resnet.py:41-70 / :79-80 / :112-118, the chain the reference's eager modules launch:
+//   forward : batch mean/var -> normalise (read+write) -> [+= residual (2 reads + write)] -> ReLU (read+write)
+//   backward: ReLU-bwd (2 reads + write) -> dscale/dbias (2 reads) -> dx (2-3 reads + write)
+// (measured round 1: 58 % of the MI355X step time) with
+//   forward : 1 read (statistics) + 1 read [+1 residual read] + 1 write
+//   backward: 3 reads (reduce) + 3 reads + 1 write [+1 write for the residual branch]
+// All of it is HBM-bound streaming: activations are [M = N*H*W rows][C channels] with C contiguous (NHWC), so a
+// thread owns 8 (bf16) / 4 (f32) consecutive channels = one 16-byte load per row and walks rows with a stride;
+// per-channel constants live in registers; partial sums go through LDS once per workgroup and through a small
+// [row-blocks][C] float buffer once per launch (no atomics -> bit-reproducible), combined in float64.
+#include "dir_common.h"
+
+namespace {
+
+struct BnGeom {
+    int ct;             // channel tile handled by one workgroup column (<= 256 for bf16, <= 128 for f32)
+    int tpr;            // threads per row inside the tile = ct / VEC
+    int rpi;            // rows per iteration = 256 / tpr
+    int ctiles;         // C / ct
+    int rblocks;        // row blocks (grid.x)
+};
+
+template <int VEC>
+BnGeom bn_geom(int64_t M, int C) {
+    BnGeom g;
+    const int max_ct = 32 * VEC;                        // 32 lanes x 16 B = 512 B contiguous per row segment
+    g.ct = C < max_ct ? C : max_ct;
+    g.tpr = g.ct / VEC;
+    g.rpi = DIR_TPB / g.tpr;
+    g.ctiles = C / g.ct;
+    int64_t want = (M + (int64_t)g.rpi * 4 - 1) / ((int64_t)g.rpi * 4);   // >= 4 row iterations per workgroup
+    int64_t cap = 1024 / g.ctiles; if (cap < 1) cap = 1;   // <= 1024 workgroups, <= 1024/ctiles partial rows per channel
+    g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    return g;
+}
+
+// ---- 16-byte vector load/store of VEC elements as float ------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+};
+struct bf16_t { uint16_t v; };
+__device__ __forceinline__ uint32_t f2bf(float f) {           // round to nearest even, NaN kept quiet
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = f2bf(o[2 * i]) | (f2bf(o[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// Workgroup reduction of per-thread [VEC] partials over the rpi row-lanes that share a channel group, then one
+// store per channel into partial[rblock][which][C].
+template <int VEC, int NACC>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NACC][VEC], int tpr, int rpi, int C, int c0,
+                                                   float* __restrict__ partial, int nacc_stride_c) {
+    __shared__ float sh[NACC][DIR_TPB * VEC];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sh[a][t * VEC + j] = acc[a][j];
+    __syncthreads();
+    if (t < tpr) {                                       // row-lane 0 of each channel group sums the others
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            float s[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] = 0.0f;
+            for (int r = 0; r < rpi; ++r)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s[j] += sh[a][(r * tpr + t) * VEC + j];
+            float* o = partial + ((size_t)blockIdx.x * NACC + a) * nacc_stride_c + c0 + t * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = s[j];
+        }
+    }
+}
+
+// ---- forward: statistics -------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_stats_partial_kernel(const T* __restrict__ x, int64_t M, int C, BnGeom g, float* __restrict__ partial) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c0 = blockIdx.y * g.ct;
+    const T* base = x + c0 + tg * VEC;
+    float acc[2][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + 3 * stride < M; row += 4 * stride) {     // 4 independent 16-B loads in flight per lane
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec<T>::load(base + (row + u * stride) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { acc[0][j] += v[u][j]; acc[1][j] += v[u][j] * v[u][j]; }
+    }
+    for (; row < M; row += stride) {
+        float v[VEC]; Vec<T>::load(base + row * C, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { acc[0][j] += v[j]; acc[1][j] += v[j] * v[j]; }
+    }
+    block_reduce_store<VEC, 2>(acc, g.tpr, g.rpi, C, c0, partial, C);
+}
+
+
+// Sum partial[b][which][c] over b for 8 channels per workgroup: 256 threads = 8 channels x 32 slices of the
+// row-block axis, float64, LDS tree. Returns the two sums for channel (blockIdx.x*8 + (t & 7)) in lanes t < 8.
+#define FIN_CH 8
+#define FIN_SL (DIR_TPB / FIN_CH)
+__device__ __forceinline__ bool column_sums(const float* __restrict__ partial, int rblocks, int C, double& s0, double& s1) {
+    __shared__ double sh[2][DIR_TPB];
+    const int t = threadIdx.x, ch = t & (FIN_CH - 1), sl = t / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + ch;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = sl; r < rblocks; r += FIN_SL) {
+            a += (double)partial[((size_t)r * 2 + 0) * C + c];
+            b += (double)partial[((size_t)r * 2 + 1) * C + c];
+        }
+    }
+    sh[0][t] = a; sh[1][t] = b;
+    __syncthreads();
+    if (t >= FIN_CH || c >= C) return false;
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < FIN_SL; ++k) { a += sh[0][k * FIN_CH + t]; b += sh[1][k * FIN_CH + t]; }
+    s0 = a; s1 = b;
+    return true;
+}
+
+// coef layout in the workspace: [0][C] = a (scale), [1][C] = b (shift)
+__global__ void __launch_bounds__(DIR_TPB)
+bn_finalize_train_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
+                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                         double momentum, double eps, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                         float* __restrict__ coef) {
+    double s, q;
+    if (!column_sums(partial, rblocks, C, s, q)) return;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x;
+    const double n = (double)M;
+    const double mean = s / n;
+    double var = q / n - mean * mean;                     // biased (normalisation)
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)rstd;
+    if (running_mean) {                                    // torch: running = (1-m)*running + m*batch, unbiased var
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+    const float a = (float)((double)gamma[c] * rstd);
+    coef[c] = a;
+    coef[C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+}
+
+__global__ void __launch_bounds__(DIR_TPB)
+bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                        const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                        double eps, float* __restrict__ coef) {
+    const int c = blockIdx.x * DIR_TPB + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)running_var[c] + eps);
+    coef[c] = (float)((double)gamma[c] * rstd);
+    coef[C + c] = (float)((double)beta[c] - (double)running_mean[c] * (double)gamma[c] * rstd);
+}
+
+// ---- forward: y = [relu]( x * a + b [+ residual] ) ---------------------------------------------------------
+template <typename T, bool RES, bool RELU>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t M, int C, BnGeom g,
+                const float* __restrict__ coef) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c = blockIdx.y * g.ct + tg * VEC;
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; b[j] = coef[C + c + j]; }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    // Mirrored row order (physical row = M-1-row): the statistics pass swept the tensor front to back, so its
+    // tail is what L2 / the 256 MiB Infinity Cache still hold — re-read that first.
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + stride < M; row += 2 * stride) {
+        float v[2][VEC], r[2][VEC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Vec<T>::load(x + (M - 1 - (row + u * stride)) * C + c, v[u]);
+            if (RES) Vec<T>::load(res + (M - 1 - (row + u * stride)) * C + c, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float o = v[u][j] * a[j] + b[j];
+                if (RES) o += r[u][j];
+                if (RELU) o = o > 0.0f ? o : 0.0f;
+                v[u][j] = o;
+            }
+            Vec<T>::store(y + (M - 1 - (row + u * stride)) * C + c, v[u]);
+        }
+    }
+    for (; row < M; row += stride) {
+        float v[VEC], r[VEC];
+        Vec<T>::load(x + (M - 1 - row) * C + c, v);
+        if (RES) Vec<T>::load(res + (M - 1 - row) * C + c, r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float o = v[j] * a[j] + b[j];
+            if (RES) o += r[j];
+            if (RELU) o = o > 0.0f ? o : 0.0f;
+            v[j] = o;
+        }
+        Vec<T>::store(y + (M - 1 - row) * C + c, v);
+    }
+}
+
+// ---- backward: g = dout * [out > 0];  partial sums of g and g * x ------------------------------------------
+template <typename T, bool RELU>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ out,
+                      int64_t M, int C, BnGeom g, float* __restrict__ partial) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c0 = blockIdx.y * g.ct, c = c0 + tg * VEC;
+    float acc[2][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + stride < M; row += 2 * stride) {
+        float d[2][VEC], v[2][VEC], o[2][VEC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Vec<T>::load(dout + (row + u * stride) * C + c, d[u]);
+            Vec<T>::load(x + (row + u * stride) * C + c, v[u]);
+            if (RELU) Vec<T>::load(out + (row + u * stride) * C + c, o[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                acc[0][j] += gj; acc[1][j] += gj * v[u][j];
+            }
+    }
+    for (; row < M; row += stride) {
+        float d[VEC], v[VEC], o[VEC];
+        Vec<T>::load(dout + row * C + c, d);
+        Vec<T>::load(x + row * C + c, v);
+        if (RELU) Vec<T>::load(out + row * C + c, o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            acc[0][j] += gj; acc[1][j] += gj * v[j];
+        }
+    }
+    block_reduce_store<VEC, 2>(acc, g.tpr, g.rpi, C, c0, partial, C);
+}
+
+// dbeta = sum g;  dgamma = rstd * (sum g*x - mean * sum g);  dx = a*g + p*x + q with
+// a = gamma*rstd, p = -a*rstd*dgamma/M, q = -a*dbeta/M - p*mean.   coef: [0]=a [1]=p [2]=q
+__global__ void __launch_bounds__(DIR_TPB)
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
+                       const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                       const float* __restrict__ save_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                       float* __restrict__ coef) {
+    double sg, sgx;
+    if (!column_sums(partial, rblocks, C, sg, sgx)) return;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x;
+    const double mean = (double)save_mean[c], rstd = (double)save_rstd[c], n = (double)M;
+    const double dg = rstd * (sgx - mean * sg);
+    dbeta[c] = (float)sg;
+    dgamma[c] = (float)dg;
+    const double a = (double)gamma[c] * rstd;
+    const double p = -a * rstd * dg / n;
+    coef[c] = (float)a;
+    coef[C + c] = (float)p;
+    coef[2 * C + c] = (float)(-a * sg / n - p * mean);
+}
+
+template <typename T, bool RELU, bool DRES>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ out,
+                    T* __restrict__ dx, T* __restrict__ dres, int64_t M, int C, BnGeom g, const float* __restrict__ coef) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c = blockIdx.y * g.ct + tg * VEC;
+    float a[VEC], p[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; p[j] = coef[C + c + j]; q[j] = coef[2 * C + c + j]; }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + stride < M; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
+        float d[2][VEC], v[2][VEC], o[2][VEC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t pr = M - 1 - (row + u * stride);
+            Vec<T>::load(dout + pr * C + c, d[u]);
+            Vec<T>::load(x + pr * C + c, v[u]);
+            if (RELU) Vec<T>::load(out + pr * C + c, o[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t pr = M - 1 - (row + u * stride);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                d[u][j] = gj;
+                v[u][j] = a[j] * gj + (p[j] * v[u][j] + q[j]);
+            }
+            Vec<T>::store(dx + pr * C + c, v[u]);
+            if (DRES) Vec<T>::store(dres + pr * C + c, d[u]);
+        }
+    }
+    for (; row < M; row += stride) {
+        const int64_t pr = M - 1 - row;
+        float d[VEC], v[VEC], o[VEC];
+        Vec<T>::load(dout + pr * C + c, d);
+        Vec<T>::load(x + pr * C + c, v);
+        if (RELU) Vec<T>::load(out + pr * C + c, o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            d[j] = gj;
+            v[j] = a[j] * gj + (p[j] * v[j] + q[j]);
+        }
+        Vec<T>::store(dx + pr * C + c, v);
+        if (DRES) Vec<T>::store(dres + pr * C + c, d);
+    }
+}
+
+struct BnWs { float* partial; float* coef; size_t bytes; };
+template <int VEC> BnWs bn_ws(void* base, int64_t M, int C) {
+    BnGeom g = bn_geom<VEC>(M, C);
+    BnWs w;
+    const size_t pbytes = dir_align_up(sizeof(float) * (size_t)g.rblocks * 2 * C, 256);
+    w.partial = reinterpret_cast<float*>(base);
+    w.coef = reinterpret_cast<float*>(static_cast<char*>(base) + pbytes);
+    w.bytes = pbytes + dir_align_up(sizeof(float) * 3 * (size_t)C, 256);
+    return w;
+}
+
+bool bn_shape_ok(int dtype, int64_t M, int C) {
+    const int vec = dtype == DIR_BF16 ? 8 : 4;
+    if (M <= 0 || C <= 0 || C % vec) return false;
+    const int max_ct = 32 * vec;
+    return C <= max_ct ? (DIR_TPB % (C / vec) == 0) : (C % max_ct == 0);
+}
+
+template <typename T>
+int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const float* gamma, const float* beta,
+             float* running_mean, float* running_var, double momentum, double eps, int relu, bool training,
+             float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, hipStream_t s) {
+    constexpr int VEC = Vec<T>::N;
+    const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
+    BnGeom g = bn_geom<VEC>(M, C);
+    BnWs w = bn_ws<VEC>(ws, M, C);
+    DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
+    const int cblocks = dir_cdiv(C, DIR_TPB);
+    if (training) {
+        hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
+        DIR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(dir_cdiv(C, FIN_CH)), dim3(DIR_TPB), 0, s, w.partial, g.rblocks, M, C, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
+    }
+    DIR_LAUNCH_CHECK();
+    const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+template <typename T>
+int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, void* dres_, int64_t M, int C,
+             const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int relu,
+             void* ws, size_t ws_bytes, hipStream_t s) {
+    constexpr int VEC = Vec<T>::N;
+    const T* dout = static_cast<const T*>(dout_); const T* x = static_cast<const T*>(x_); const T* out = static_cast<const T*>(out_);
+    T* dx = static_cast<T*>(dx_); T* dres = static_cast<T*>(dres_);
+    BnGeom g = bn_geom<VEC>(M, C);
+    BnWs w = bn_ws<VEC>(ws, M, C);
+    DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
+    const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, true>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, false>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dir_cdiv(C, FIN_CH)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
+                       save_mean, save_rstd, dgamma, dbeta, w.coef);
+    DIR_LAUNCH_CHECK();
+    if (relu && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
+    else if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
+    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dir_bn_workspace(int dtype, int64_t M, int C) {
+    if (!bn_shape_ok(dtype, M, C)) return 0;
+    return dtype == DIR_BF16 ? bn_ws<8>(nullptr, M, C).bytes : bn_ws<4>(nullptr, M, C).bytes;
+}
+
+extern "C" int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                double momentum, double eps, int relu, float* save_mean, float* save_rstd,
+                                void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF((running_mean == nullptr) != (running_var == nullptr), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return fwd_impl<bf16_t>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, relu, true,
+                                save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream));
+    return fwd_impl<float>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, relu, true,
+                           save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream));
+}
+
+extern "C" int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                               const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                               double eps, int relu, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !gamma || !beta || !running_mean || !running_var || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    float* rm = const_cast<float*>(running_mean); float* rv = const_cast<float*>(running_var);
+    if (dtype == DIR_BF16)
+        return fwd_impl<bf16_t>(x, residual, y, M, C, gamma, beta, rm, rv, 0.0, eps, relu, false, nullptr, nullptr,
+                                workspace, workspace_bytes, dir_s(stream));
+    return fwd_impl<float>(x, residual, y, M, C, gamma, beta, rm, rv, 0.0, eps, relu, false, nullptr, nullptr,
+                           workspace, workspace_bytes, dir_s(stream));
+}
+
+extern "C" int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void* dres, int dtype,
+                          int64_t M, int C, const float* gamma, const float* save_mean, const float* save_rstd,
+                          float* dgamma, float* dbeta, int relu, void* workspace, size_t workspace_bytes,
+                          dir_stream_t stream) {
+    DIR_RETURN_IF(!dout || !x || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(relu && !out, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(dout) || !dir_aligned16(x) || !dir_aligned16(dx) || (out && !dir_aligned16(out)) ||
+                  (dres && !dir_aligned16(dres)), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return bwd_impl<bf16_t>(dout, x, out, dx, dres, M, C, gamma, save_mean, save_rstd, dgamma, dbeta, relu,
+                                workspace, workspace_bytes, dir_s(stream));
+    return bwd_impl<float>(dout, x, out, dx, dres, M, C, gamma, save_mean, save_rstd, dgamma, dbeta, relu,
+                           workspace, workspace_bytes, dir_s(stream));
+}

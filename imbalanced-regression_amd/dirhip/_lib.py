@@ -37,6 +37,13 @@ SIGNATURES = {
     "dir_weighted_loss": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dir_bn_workspace": (c_size_t, [c_int, c_int64, c_int]),
+    "dir_bn_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_fwd_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_double, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 

@@ -1,0 +1,92 @@
+"""Fused BatchNorm2d (+ residual add) (+ ReLU) for channels_last activations — one autograd node per BN layer,
+three HIP launches forward (statistics, finalize, apply) and three backward (reduce, finalize, apply) instead of
+MIOpen BatchNorm + separate add / ReLU / ReLU-backward kernels (``dir_bn_*`` in ``include/dir_hip.h``).
+
+``bn_act(x, bn, relu, residual)`` reads its parameters and running statistics from the ``nn.BatchNorm2d`` module
+``bn`` that ``resnet.py`` registers (so state_dict keys and checkpoint compatibility are untouched) and implements
+exactly ``relu(bn(x) + residual)`` with torch's BatchNorm semantics (biased variance for normalisation, unbiased
+for ``running_var``, ``momentum`` blend, ``num_batches_tracked += 1``).
+"""
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.DIR_BF16, torch.float32: L.DIR_F32}
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _ws(dtype_code, m, c, device):
+    n = L.lib().dir_bn_workspace(dtype_code, m, c)
+    if n == 0:
+        raise L.DirHipError(f"dir_bn: unsupported shape M={m} C={c}")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training):
+        if not x.is_cuda:
+            raise L.DirHipError(f"bn_act: input on {x.device}; the fused BatchNorm runs only as HIP kernels (no CPU fallback)")
+        x = _nhwc(x)
+        if residual is not None:
+            residual = _nhwc(residual)
+            if residual.dtype != x.dtype:
+                residual = residual.to(x.dtype)
+        n, c, h, w = x.shape
+        m = n * h * w
+        code = _DT[x.dtype]
+        y = torch.empty_like(x)
+        ws = _ws(code, m, c, x.device)
+        stream = L.stream_ptr(x.device)
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            L.check(L.lib().dir_bn_fwd_train(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
+                                             L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
+                                             int(relu), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), stream),
+                    "dir_bn_fwd_train")
+            ctx.save_for_backward(x, gamma, y if relu else None, mean, rstd)
+            ctx.relu = bool(relu)
+            ctx.has_res = residual is not None
+        else:
+            L.check(L.lib().dir_bn_fwd_eval(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
+                                            L.ptr(running_mean), L.ptr(running_var), float(eps), int(relu), L.ptr(ws),
+                                            ws.numel(), stream), "dir_bn_fwd_eval")
+            ctx.eval_mode = True
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        if getattr(ctx, "eval_mode", False):
+            raise NotImplementedError("bn_act backward in eval mode is not implemented (the reference never needs it)")
+        x, gamma, y, mean, rstd = ctx.saved_tensors
+        dout = _nhwc(dout)
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        n, c, h, w = x.shape
+        m = n * h * w
+        code = _DT[x.dtype]
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _ws(code, m, c, x.device)
+        L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
+                                   L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(ctx.relu), L.ptr(ws),
+                                   ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def bn_act(x, bn, relu=True, residual=None):
+    """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``."""
+    training = bn.training or (bn.running_mean is None)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not implemented")
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training)

@@ -6,9 +6,10 @@ reference checkpoints load), same initialisation stream, same forward contract
 (``(pred, encoding)`` when training with FDS, else ``pred``; the returned ``encoding`` is the tensor
 ``FDS.smooth`` calibrated in place — SURVEY A.2).
 
-Round-1 backbone: the conv/BN/ReLU stack is expressed with torch.nn modules (MIOpen / hipBLASLt
-MFMA implicit-GEMM under bf16 autocast + channels_last, driven by ``dirhip.engine``); the
-pool -> FDS calibrate -> linear -> weighted-loss tail is the hand-written HIP path and always fp32.
+Backbone: convolutions are bf16 MFMA implicit-GEMM library kernels (MIOpen, channels_last, driven by
+``dirhip.parallel.DataParallelEngine``'s autocast); every BatchNorm (+ residual add) (+ ReLU) is ONE fused
+hand-written HIP node (``dirhip.bn.bn_act`` -> ``dir_bn_*``); the pool -> FDS calibrate -> linear -> weighted-loss
+tail is the hand-written HIP path and always fp32. GPU only (no CPU fallback).
 """
 import logging
 import math
@@ -16,6 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .bn import bn_act
 from .fds import FDS
 
 print = logging.info
@@ -39,12 +41,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        y += shortcut
-        return self.relu(y)
+        shortcut = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        y = bn_act(self.conv1(x), self.bn1, relu=True)
+        y = bn_act(self.conv2(y), self.bn2, relu=True)
+        return bn_act(self.conv3(y), self.bn3, relu=True, residual=shortcut)      # relu(bn3(.) + shortcut)
 
 
 class ResNet(nn.Module):
@@ -99,7 +99,7 @@ class ResNet(nn.Module):
 
     def features(self, x):
         """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.conv1(x), self.bn1, relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
         return x.view(x.size(0), -1)

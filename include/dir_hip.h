@@ -180,6 +180,35 @@ int dir_scale_by_device_scalar(const float* in, const float* scalar, float* out,
 int dir_lds_weights(const double* labels, int64_t n, int max_target, int reweight, int lds,
                     const double* window, int ks, float* weights);
 
+/* ---------------------------------------------------------------------------------------------
+ * K9a  BatchNorm2d (+ residual add) (+ ReLU), NHWC activations, training and eval forward, backward.
+ * Replaces, for each of the 53 BN layers of imdb-wiki-dir/resnet.py (Bottleneck.forward :57-70, stem :128-130,
+ * downsample :114-117), the eager chain  bn -> [+= residual] -> relu  and its autograd
+ * (MIOpen BatchNorm fwd/bwd + 3 element-wise torch kernels: 58 % of the round-1 step time).
+ *   x, residual, y, dout, out, dx, dres: [M, C] with C contiguous (a channels_last NCHW tensor), dtype
+ *   DIR_BF16 or DIR_F32, 16-byte aligned; M = N*H*W.  C % 8 == 0 (bf16) / % 4 (f32).
+ *   gamma, beta, running_*, save_*, dgamma, dbeta: [C] f32.
+ * train fwd:  mean/var over M (biased var for the normalisation; running_var gets the unbiased one, torch
+ *             semantics; running_* may both be NULL), save_mean / save_rstd for the backward,
+ *             y = [relu]((x - mean) * rstd * gamma + beta [+ residual]).
+ * eval fwd :  same with the running statistics.
+ * bwd      :  g = relu ? dout * (out > 0) : dout;  dbeta = sum g;  dgamma = sum g * xhat;
+ *             dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) = g.
+ * workspace: >= dir_bn_workspace(dtype, M, C) bytes (0 = unsupported shape), 256-byte aligned.
+ */
+size_t dir_bn_workspace(int dtype, int64_t M, int C);
+int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     double momentum, double eps, int relu, float* save_mean, float* save_rstd,
+                     void* workspace, size_t workspace_bytes, dir_stream_t stream);
+int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                    const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    double eps, int relu, void* workspace, size_t workspace_bytes, dir_stream_t stream);
+int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void* dres, int dtype,
+               int64_t M, int C, const float* gamma, const float* save_mean, const float* save_rstd,
+               float* dgamma, float* dbeta, int relu, void* workspace, size_t workspace_bytes,
+               dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

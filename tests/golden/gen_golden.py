@@ -259,6 +259,82 @@ def gen_resnet():
          n_params=np.array(sum(p.numel() for p in model.parameters())))
 
 
+def gen_train_trajectory():
+    """End-to-end: the reference's own resnet50 + FDS + weighted_l1_loss + Adam driven by train.py:246-262 /
+    :269-281 verbatim on CPU fp32 (a) BASELINE configs[0]: AgeDB defaults, LDS only, B=8; (b) IMDB-WIKI defaults,
+    LDS + FDS, 3 epochs x 2 steps of B=6 + epoch tails. Losses per step + FDS buffers of the bins that occur."""
+    ref = refshim.load("agedb-dir")
+    import pandas as pd
+    df = pd.read_csv(os.path.join(refshim.REFERENCE_ROOT, "agedb-dir/data/agedb.csv"))
+    ages = df[df["split"] == "train"]["age"].values
+    w_all = np.asarray(refshim.prepare_weights(ages, "agedb-dir", reweight="sqrt_inv", lds=True, lds_kernel="gaussian", lds_ks=5, lds_sigma=2), dtype=np.float32)
+    out = {}
+    # ---- (a) config 1
+    rows = np.random.default_rng(0).choice(len(ages), 8, replace=False)
+    torch.manual_seed(11)
+    model = refshim.make_resnet50("agedb-dir", fds=False, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1,
+                                  kernel="gaussian", ks=9, sigma=1, momentum=0.9)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    y = torch.tensor(ages[rows], dtype=torch.float32).view(-1, 1)
+    w = torch.tensor(w_all[rows]).view(-1, 1)
+    losses = []
+    model.train()
+    for _ in range(4):
+        o = model(x, y, 0)
+        loss = ref.loss.weighted_l1_loss(o, y, w)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    out.update(a_rows=rows, a_labels=y.numpy(), a_weights=w.numpy(), a_ref_losses=np.array(losses))
+    # ---- (b) LDS + FDS, run twice: exact inputs and inputs perturbed by 1e-6 relative noise. ResNet-50 + BN at
+    # B=6 is chaotic (the second run diverges from the first by ~1e-4 after one step and ~1e-2 after five), so the
+    # perturbed run is the yardstick for what "the same trajectory" can mean across two conv libraries.
+    kw = dict(bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9)
+    bins = np.array([25, 26, 27, 31, 40])
+    labels = [torch.tensor([[25.0], [40.0], [25.0], [31.0], [40.0], [26.0 + i]]) for i in range(2)]
+
+    def run_b(noise):
+        torch.manual_seed(12)
+        model = refshim.make_resnet50("imdb-wiki-dir", fds=True, **kw)
+        # --optimizer sgd (train.py:163-164): updates proportional to the gradient (Adam's g/sqrt(g^2) first steps
+        # turn 1e-6 gradient noise into +-lr sign flips, which is even more chaotic)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(1)
+        batches = [(torch.randn(6, 3, 224, 224, generator=g), labels[i], torch.rand(6, 1, generator=g) + 0.5) for i in range(2)]
+        weights = np.stack([b[2].numpy() for b in batches])
+        if noise:
+            gn = torch.Generator().manual_seed(5)
+            batches = [(x * (1 + noise * torch.randn(x.shape, generator=gn)), y, w) for x, y, w in batches]
+        losses = []
+        for epoch in range(3):
+            model.train()
+            for xb, yb, wb in batches:
+                with refshim.cuda_identity():
+                    o, _ = model(xb, yb, epoch)
+                loss = ref.loss.weighted_l1_loss(o, yb, wb)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item())
+            enc, lab = [], []
+            with torch.no_grad(), refshim.cuda_identity():
+                for xb, yb, _ in batches:
+                    _, f = model(xb, yb, epoch)
+                    enc.extend(f.data.squeeze().cpu().numpy()); lab.extend(yb.data.squeeze().cpu().numpy())
+                model.FDS.update_last_epoch_stats(epoch)
+                model.FDS.update_running_stats(torch.from_numpy(np.vstack(enc)), torch.from_numpy(np.hstack(lab)), epoch)
+        F = model.FDS
+        return dict(losses=np.array(losses), weights=weights, running_mean=F.running_mean[bins].numpy().copy(),
+                    running_var=F.running_var[bins].numpy().copy(), smoothed_mean=F.smoothed_mean_last_epoch[bins].numpy().copy(),
+                    tracked=F.num_samples_tracked.numpy().copy(), epoch=F.epoch.numpy().copy())
+    r0, r1 = run_b(0.0), run_b(1e-6)
+    out.update(b_weights=r0["weights"], b_labels=np.stack([l.numpy() for l in labels]), b_bins=bins,
+               b_ref_losses=r0["losses"], b_ref_running_mean=r0["running_mean"], b_ref_running_var=r0["running_var"],
+               b_ref_smoothed_mean=r0["smoothed_mean"], b_ref_tracked=r0["tracked"], b_ref_epoch=r0["epoch"],
+               b_pert_losses=r1["losses"], b_pert_running_mean=r1["running_mean"], b_pert_running_var=r1["running_var"],
+               b_pert_smoothed_mean=r1["smoothed_mean"])
+    save("train_trajectory.npz", **out)
+    print("trajectory losses", out["a_ref_losses"], out["b_ref_losses"])
+
+
 def main():
     ref = refshim.load("imdb-wiki-dir")
     gen_windows(ref)
@@ -268,6 +344,7 @@ def main():
     gen_calibrate(ref)
     gen_losses(ref)
     gen_resnet()
+    gen_train_trajectory()
     manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
                 "agedb_sqrtinv_lds_g52_sha256_prefix": sha,
                 "files": sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))}

@@ -1,0 +1,109 @@
+"""-m gpu: fused BatchNorm(+residual)(+ReLU) HIP kernels vs a plain PyTorch fp32 reference of the same op
+(F.batch_norm -> + residual -> relu, autograd backward), on ResNet-50's layer shapes, bf16 and f32, and the
+whole dirhip ResNet-50 (fp32 mode) vs the reference's CPU forward golden."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, res, bn_w, bn_b, rm, rv, relu, training, momentum=0.1, eps=1e-5):
+    y = F.batch_norm(x, rm, rv, bn_w, bn_b, training, momentum, eps)
+    if res is not None:
+        y = y + res
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,relu,has_res", [((8, 64, 56, 56), True, False), ((8, 256, 56, 56), True, True),
+                                                ((4, 512, 28, 28), False, False), ((6, 1024, 14, 14), True, True),
+                                                ((5, 2048, 7, 7), True, True), ((3, 64, 112, 112), True, False),
+                                                ((2, 128, 9, 5), False, True), ((2, 8, 3, 2), True, False)])
+def test_bn_act_train_fwd_bwd(dtype, shape, relu, has_res):
+    from dirhip.bn import bn_act
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    n, c, h, w = shape
+    x32 = (torch.randn(shape, device="cuda", generator=g) * 1.7 + 0.3).contiguous(memory_format=torch.channels_last)
+    r32 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last) if has_res else None
+    dy32 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, device="cuda", generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, device="cuda", generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(c, device="cuda", generator=g) * 0.1)
+    # inputs rounded to the kernel dtype so both sides see identical values
+    x = x32.to(dtype).requires_grad_(True)
+    r = r32.to(dtype).requires_grad_(True) if has_res else None
+    dy = dy32.to(dtype)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    y = bn_act(x, bn, relu=relu, residual=r)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    # fp32 reference of the same op
+    xr = x.detach().float().requires_grad_(True)
+    rr = r.detach().float().requires_grad_(True) if has_res else None
+    wr, br = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    yr = _ref(xr, rr, wr, br, rm, rv, relu, True)
+    yr.backward(dy.float())
+    tol = dict(rtol=1e-5, atol_scale=2e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol_scale=4e-3)
+    assert_close(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), msg="y", **tol)
+    assert_close(bn.running_mean.cpu().numpy(), rm.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, msg="running_mean")
+    assert_close(bn.running_var.cpu().numpy(), rv.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, msg="running_var")
+    assert int(bn.num_batches_tracked) == 1
+    gt = dict(rtol=1e-4, atol_scale=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
+    if dtype == torch.bfloat16 and relu:
+        # the ReLU mask is taken from the bf16-rounded output: elements whose fp32 pre-activation is within bf16
+        # round-off of 0 may flip; compare on the elements where both masks agree (all but a handful)
+        agree = ((y.detach().float() > 0) == (yr.detach() > 0))
+        assert agree.float().mean() > 0.999
+    assert_close(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), msg="dx", **gt)
+    if has_res:
+        assert_close(r.grad.float().cpu().numpy(), rr.grad.cpu().numpy(), msg="dres", **gt)
+    assert_close(bn.weight.grad.cpu().numpy(), wr.grad.cpu().numpy(), msg="dgamma", **gt)
+    assert_close(bn.bias.grad.cpu().numpy(), br.grad.cpu().numpy(), msg="dbeta", **gt)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_eval(dtype):
+    from dirhip.bn import bn_act
+    g = torch.Generator(device="cuda").manual_seed(1)
+    shape = (4, 256, 14, 14)
+    x = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last).to(dtype)
+    r = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last).to(dtype)
+    bn = nn.BatchNorm2d(256).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(256, device="cuda", generator=g) * 0.3)
+        bn.running_var.copy_(torch.rand(256, device="cuda", generator=g) + 0.5)
+        bn.weight.copy_(torch.rand(256, device="cuda", generator=g) + 0.5)
+        y = bn_act(x, bn, relu=True, residual=r)
+        yr = _ref(x.float(), r.float(), bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False)
+    tol = dict(rtol=1e-5, atol_scale=2e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol_scale=4e-3)
+    assert_close(y.float().cpu().numpy(), yr.cpu().numpy(), **tol)
+    assert int(bn.num_batches_tracked) == 0
+
+
+def test_resnet50_forward_fp32_vs_reference_golden(golden):
+    """dirhip ResNet-50 on the MI355X in fp32 (MIOpen convs + fused HIP BN nodes + HIP tail) vs the reference's
+    CPU fp32 forward (golden): eval and train mode, same seeded init stream and input."""
+    from dirhip.resnet import resnet50
+    g = golden("resnet50_forward.npz")
+    torch.manual_seed(1234)
+    m = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian",
+                 ks=5, sigma=2, momentum=0.9).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(99)).cuda().contiguous(memory_format=torch.channels_last)
+    m.eval()
+    with torch.no_grad():
+        p = m(x)
+    assert_close(p.cpu().numpy(), g["ref_pred_eval"], rtol=2e-3, atol_scale=2e-3, msg="eval pred")
+    m.train()
+    with torch.no_grad():
+        out = m(x, torch.tensor([[31.0], [64.0]], device="cuda"), 0)
+    assert isinstance(out, tuple) and out[1].shape == (2, 2048)
+    assert_close(out[0].cpu().numpy(), g["ref_pred_train"], rtol=2e-3, atol_scale=2e-3, msg="train pred")
+    assert_close(out[1].cpu().numpy(), g["ref_enc_train"], rtol=2e-3, atol_scale=2e-3, msg="train encoding")

@@ -118,8 +118,7 @@ def test_no_cpu_fallback():
 
 
 def test_resnet50_matches_reference_golden(golden):
-    """Architecture, state_dict keys, init stream and forward contract of resnet.py (CPU fp32, bit-exact:
-    the conv stack is torch modules in both; the FDS branch is not taken at epoch 0)."""
+    """Architecture, state_dict keys and init stream of resnet.py (same torch RNG stream as the reference)."""
     from dirhip.resnet import resnet50
     g = golden("resnet50_forward.npz")
     torch.manual_seed(1234)
@@ -129,18 +128,10 @@ def test_resnet50_matches_reference_golden(golden):
     assert list(sd.keys()) == [str(k) for k in g["keys"]]
     assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 23510081
     np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["ref_param_sums"], rtol=1e-11, atol=1e-11)
-    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(99))
-    m.eval()
-    with torch.no_grad():
-        p = m(x)
-    assert isinstance(p, torch.Tensor) and p.shape == (2, 1)
-    assert_close(p.numpy(), g["ref_pred_eval"], rtol=1e-5)
-    m.train()
-    with torch.no_grad():
-        out = m(x, torch.tensor([[31.0], [64.0]]), 0)
-    assert isinstance(out, tuple) and out[1].shape == (2, 2048)
-    assert_close(out[0].numpy(), g["ref_pred_train"], rtol=1e-5)
-    assert_close(out[1].numpy(), g["ref_enc_train"], rtol=1e-5)
+    # the forward itself is GPU-only (fused HIP BatchNorm nodes): tests/test_hip_bn.py checks it against the golden
+    from dirhip import _lib
+    with pytest.raises(_lib.DirHipError):
+        m(torch.randn(1, 3, 224, 224))
 
 
 # ---- world_size 2 over gloo: the per-epoch FDS statistic exchange -------------------------
