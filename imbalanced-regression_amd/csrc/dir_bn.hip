@@ -374,7 +374,8 @@ bool bn_shape_ok(int dtype, int64_t M, int C) {
 template <typename T>
 int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const float* gamma, const float* beta,
              float* running_mean, float* running_var, double momentum, double eps, int relu, bool training,
-             float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, hipStream_t s) {
+             float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, hipStream_t s,
+             const float* ext_partial = nullptr, int ext_rows = 0) {
     constexpr int VEC = Vec<T>::N;
     const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
     BnGeom g = bn_geom<VEC>(M, C);
@@ -382,9 +383,14 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
     const int cblocks = dir_cdiv(C, DIR_TPB);
     if (training) {
-        hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
-        DIR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(dir_cdiv(C, FIN_CH)), dim3(DIR_TPB), 0, s, w.partial, g.rblocks, M, C, gamma, beta,
+        const float* part = w.partial;
+        int prow = g.rblocks;
+        if (ext_partial) { part = ext_partial; prow = ext_rows; }       // statistics came out of the conv epilogue
+        else {
+            hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
+            DIR_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(dir_cdiv(C, FIN_CH)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
     } else {
         hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
@@ -445,6 +451,23 @@ extern "C" int dir_bn_fwd_train(const void* x, const void* residual, void* y, in
                                 save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream));
     return fwd_impl<float>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, relu, true,
                            save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream));
+}
+
+extern "C" int dir_bn_fwd_train_partials(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                                         const float* partial, int partial_rows,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         double momentum, double eps, int relu, float* save_mean, float* save_rstd,
+                                         void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || !partial || partial_rows <= 0, DIR_EINVAL);
+    DIR_RETURN_IF((running_mean == nullptr) != (running_var == nullptr), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return fwd_impl<bf16_t>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, relu, true,
+                                save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
+    return fwd_impl<float>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, relu, true,
+                           save_mean, save_rstd, workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
 }
 
 extern "C" int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,

@@ -1,0 +1,259 @@
+// MFMA implicit-GEMM convolution for NHWC bf16 activations on MI355X / gfx950 (CDNA4).
+//
+// Replaces the nn.Conv2d layers of imdb-wiki-dir/resnet.py:41-70,79,112-116 (cuDNN in the reference): the only
+// genuinely dense contraction of the hot path, so the only place MFMA is used.
+//
+//   Y[m, co] = sum_{r,s,ci} X[n, ho*stride - pad + r, wo*stride - pad + s, ci] * Wt[co, r, s, ci],   m = (n, ho, wo)
+//
+// GEMM view: M = N*Ho*Wo rows, N = Cout columns, K = R*S*Cin with Cin % 64 == 0, so one 64-wide K-step never
+// straddles a filter tap and the A-operand loader is "row pointer + bounds predicate" (zero fill at the borders).
+// Both operands are K-contiguous in memory (NHWC activations, [Cout][R][S][Cin] weights = torch channels_last), which
+// is exactly the 16-bytes-per-lane fragment of v_mfma_f32_32x32x16_bf16 — no transposes anywhere.
+//
+// Workgroup = 256 threads = 4 wavefronts (one per SIMD), tile 128 x BN x 64 (BN = 128 or 64):
+//   global -> registers (16 B per lane, next K-step prefetched while the current one is multiplied)
+//   registers -> LDS, rows of 128 B, 16-B chunks XOR-swizzled with (row >> 1) & 7 so that both the 8-lane
+//   ds_write_b128 groups and the four 16-lane ds_read_b128 groups are bank-conflict free
+//   LDS -> MFMA fragments -> 32x32x16 bf16 MFMA, fp32 accumulators (2x2 or 1x2 tiles of 32x32 per wavefront)
+//   epilogue: bf16 rounding, optional per-channel (sum, sum of squares) partials of the rounded outputs for the
+//   following BatchNorm (no separate statistics pass over Y), LDS transpose staging, 16-B coalesced row stores.
+// Workgroup ids are remapped so that the N-tiles of one M-tile run on the same XCD (A tile re-reads hit that L2).
+#include "dir_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;        // explicit global address space (no flat loads)
+__device__ __forceinline__ uint4 cv_gload(const uint16_t* base, ptrdiff_t elem_off) {
+    const u32x4 v = *reinterpret_cast<gvec_ptr>(reinterpret_cast<uintptr_t>(base + elem_off));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+struct ConvP {
+    const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+    int M, KT, cpk, ntn, nblocks;
+};
+
+constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
+
+__device__ __forceinline__ uint32_t cv_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int BN>
+__global__ void __launch_bounds__(DIR_TPB)
+conv_igemm_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
+    constexpr int B_BYTES = BN * CV_ROWB;
+    constexpr int BROWS = BN / 32;                        // B rows per loader thread
+    constexpr int MI = (BN == 128) ? 2 : 1;               // 32x32 tiles per wavefront along M
+    constexpr int NI = 2;                                 //                      ... along N
+    constexpr int WM = MI * 32;
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * A_BYTES;
+
+    // ---- workgroup -> (m tile, n tile), XCD-aware and bijective
+    int lin;
+    {
+        const int b = blockIdx.x, q = p.nblocks / 8, r = p.nblocks % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
+    const int m0 = mt * CV_BM, n0 = nt * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+
+    // ---- loader coordinates: thread loads the 16-B chunk (t & 7) of rows (t >> 3) + 32 i.
+    // Everything position dependent is computed ONCE: per row a signed element offset of its (hi0, wi0) pixel and a
+    // bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
+    const int lrow = t >> 3, lchunk = t & 7;
+    int aoff[4];
+    uint32_t amask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        aoff[i] = 0; amask[i] = 0;
+        if (m < p.M) {
+            const int wo = m % p.Wo, tmp = m / p.Wo, ho = tmp % p.Ho, n = tmp / p.Ho;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
+        }
+    }
+    const size_t K = (size_t)p.KT * CV_BK;
+    const uint16_t* wrow[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0 + lrow + 32 * i) * K + lchunk * 8;
+
+    // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch
+    int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;              // named registers: no private-memory arrays
+    rb2 = rb3 = make_uint4(0, 0, 0, 0);
+
+#define CV_LOAD_TILE()                                                                                          \
+    {                                                                                                           \
+        const int koff = (ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK;                                            \
+        const uint32_t bit = 1u << ld_tap;                                                                      \
+        /* out-of-image taps read a dummy in-bounds address (offset 0) and are zeroed after: no divergence */   \
+        const bool v0 = amask[0] & bit, v1 = amask[1] & bit, v2 = amask[2] & bit, v3 = amask[3] & bit;          \
+        ra0 = cv_gload(p.x, v0 ? (ptrdiff_t)(aoff[0] + koff) : 0);                                                                \
+        ra1 = cv_gload(p.x, v1 ? (ptrdiff_t)(aoff[1] + koff) : 0);                                                                \
+        ra2 = cv_gload(p.x, v2 ? (ptrdiff_t)(aoff[2] + koff) : 0);                                                                \
+        ra3 = cv_gload(p.x, v3 ? (ptrdiff_t)(aoff[3] + koff) : 0);                                                                \
+        rb0 = cv_gload(wrow[0], 0); wrow[0] += CV_BK;                                                   \
+        rb1 = cv_gload(wrow[1], 0); wrow[1] += CV_BK;                                                   \
+        if (BROWS == 4) {                                                                                       \
+            rb2 = cv_gload(wrow[BROWS - 2], 0); wrow[BROWS - 2] += CV_BK;                               \
+            rb3 = cv_gload(wrow[BROWS - 1], 0); wrow[BROWS - 1] += CV_BK;                               \
+        }                                                                                                       \
+        const uint32_t k0 = v0 ? ~0u : 0u, k1 = v1 ? ~0u : 0u, k2 = v2 ? ~0u : 0u, k3 = v3 ? ~0u : 0u;          \
+        ra0.x &= k0; ra0.y &= k0; ra0.z &= k0; ra0.w &= k0; ra1.x &= k1; ra1.y &= k1; ra1.z &= k1; ra1.w &= k1; \
+        ra2.x &= k2; ra2.y &= k2; ra2.z &= k2; ra2.w &= k2; ra3.x &= k3; ra3.y &= k3; ra3.z &= k3; ra3.w &= k3; \
+        if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
+    }
+#define CV_ST(base, bytes, row, v) *reinterpret_cast<uint4*>((base) + (bytes) + (row) * CV_ROWB + ((lchunk ^ (((row) >> 1) & 7)) << 4)) = (v)
+#define CV_STORE_TILE(buf)                                                                                      \
+    {                                                                                                           \
+        CV_ST(As, (buf) * A_BYTES, lrow, ra0); CV_ST(As, (buf) * A_BYTES, lrow + 32, ra1);                      \
+        CV_ST(As, (buf) * A_BYTES, lrow + 64, ra2); CV_ST(As, (buf) * A_BYTES, lrow + 96, ra3);                 \
+        CV_ST(Bs, (buf) * B_BYTES, lrow, rb0); CV_ST(Bs, (buf) * B_BYTES, lrow + 32, rb1);                      \
+        if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, lrow + 64, rb2); CV_ST(Bs, (buf) * B_BYTES, lrow + 96, rb3); } \
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+    CV_LOAD_TILE();
+    CV_STORE_TILE(0);
+    __syncthreads();
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < p.KT;
+        if (more) CV_LOAD_TILE();                              // global loads in flight during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[MI], b[NI];
+            const int chunk = kk * 2 + fhalf;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * WM + mi * 32 + frow;
+                a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wn * 64 + ni * 32 + frow;
+                b[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) CV_STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+#undef CV_LOAD_TILE
+#undef CV_STORE_TILE
+#undef CV_ST
+
+    // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
+    uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);          // [128][BN] bf16 staging (<= 32 KB, buffers are free now)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * BN * 2);   // [4 waves][2][64] column partials
+    float csum[NI], csq[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t h = cv_f2bf(acc[mi][ni][e]);
+                const int row = wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                const int col = wn * 64 + ni * 32 + frow;
+                Cs[row * BN + col] = (uint16_t)h;
+                const float v = __uint_as_float(h << 16);        // statistics of what is actually stored
+                csum[ni] += v; csq[ni] += v * v;
+            }
+    if (p.stats) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
+            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
+            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
+        }
+    }
+    __syncthreads();
+    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
+        const int which = t / BN, col = t - which * BN;
+        float s = 0.0f;
+        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
+        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
+        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
+    }
+    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
+#pragma unroll
+    for (int i = 0; i < (CV_BM * CPR) / DIR_TPB; ++i) {
+        const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
+        if (m0 + row < p.M)
+            *reinterpret_cast<uint4*>(p.y + (size_t)(m0 + row) * p.Cout + n0 + ch * 8) =
+                *reinterpret_cast<const uint4*>(Cs + row * BN + ch * 8);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
+    const long long M = (long long)N * Ho * Wo;
+    return (size_t)((M + CV_BM - 1) / CV_BM);
+}
+
+extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
+                            int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
+    DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
+    DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
+    const long long M = (long long)N * Ho * Wo;
+    DIR_RETURN_IF(M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);
+    ConvP p;
+    p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
+    p.stats = stats;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
+    const int mtiles = (int)((M + CV_BM - 1) / CV_BM);
+    const bool wide = (Cout % 128 == 0);
+    p.ntn = wide ? Cout / 128 : Cout / 64;
+    p.nblocks = mtiles * p.ntn;
+    hipStream_t s = dir_s(stream);
+    if (wide) {
+        constexpr int lds = 2 * (CV_BM * CV_ROWB + 128 * CV_ROWB);
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
+    } else {
+        constexpr int lds = 2 * (CV_BM * CV_ROWB + 64 * CV_ROWB);
+        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
+    }
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

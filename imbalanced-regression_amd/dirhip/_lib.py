@@ -40,10 +40,16 @@ SIGNATURES = {
     "dir_bn_workspace": (c_size_t, [c_int, c_int64, c_int]),
     "dir_bn_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_fwd_train_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "dir_bn_fwd_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_bn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
+    "dir_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 

@@ -27,7 +27,7 @@ def _ws(dtype_code, m, c, device):
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training, partial):
         if not x.is_cuda:
             raise L.DirHipError(f"bn_act: input on {x.device}; the fused BatchNorm runs only as HIP kernels (no CPU fallback)")
         x = _nhwc(x)
@@ -44,10 +44,17 @@ class _BNActFn(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=x.device)
             rstd = torch.empty(c, dtype=torch.float32, device=x.device)
-            L.check(L.lib().dir_bn_fwd_train(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
-                                             L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
-                                             int(relu), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), stream),
-                    "dir_bn_fwd_train")
+            if partial is not None:                  # statistics fused into the producing convolution's epilogue
+                L.check(L.lib().dir_bn_fwd_train_partials(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(partial),
+                                                          partial.shape[0], L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                                          L.ptr(running_var), float(momentum), float(eps), int(relu),
+                                                          L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), stream),
+                        "dir_bn_fwd_train_partials")
+            else:
+                L.check(L.lib().dir_bn_fwd_train(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
+                                                 L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
+                                                 int(relu), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), stream),
+                        "dir_bn_fwd_train")
             ctx.save_for_backward(x, gamma, y if relu else None, mean, rstd)
             ctx.relu = bool(relu)
             ctx.has_res = residual is not None
@@ -77,11 +84,12 @@ class _BNActFn(torch.autograd.Function):
         L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
                                    L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(ctx.relu), L.ptr(ws),
                                    ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, relu=True, residual=None):
-    """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``."""
+def bn_act(x, bn, relu=True, residual=None, partial=None):
+    """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``. ``partial`` =
+    the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only)."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -89,4 +97,5 @@ def bn_act(x, bn, relu=True, residual=None):
         raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not implemented")
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training)
+    return _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
+                          partial if training else None)

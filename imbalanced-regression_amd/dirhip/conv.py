@@ -1,0 +1,97 @@
+"""MFMA implicit-GEMM convolution (``dir_conv_fwd``) — tensor-level wrapper.
+
+``conv2d_igemm(x, w, stride, padding, want_stats)``: x ``[N, Cin, H, W]`` and w ``[Cout, Cin, R, S]``, both bf16 and
+channels_last (so their memory is NHWC / ``[Cout][R][S][Cin]``); returns y (channels_last bf16) and, optionally,
+the per-tile BatchNorm partial statistics ``[rows][2][Cout]`` float32.
+"""
+import torch
+
+from . import _lib as L
+
+
+def supported(cin, cout):
+    return cin % 64 == 0 and cout % 64 == 0
+
+
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False):
+    if not x.is_cuda:
+        raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    n, cin, h, wd = x.shape
+    cout, cin2, r, s = w.shape
+    assert cin == cin2
+    ho = (h + 2 * padding - r) // stride + 1
+    wo = (wd + 2 * padding - s) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    stats = None
+    if want_stats:
+        rows = L.lib().dir_conv_stats_rows(n, ho, wo)
+        stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dir_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), n, h, wd, cin, cout, r, s, stride, padding,
+                                 L.stream_ptr(x.device)), "dir_conv_fwd")
+    return (y, stats) if want_stats else y
+
+
+class _ConvFn(torch.autograd.Function):
+    """Forward = hand-written MFMA implicit GEMM (+ BatchNorm partial statistics in the epilogue). Backward (data and
+    weight gradients) still goes to the library convolution-backward kernels until the dgrad / wgrad MFMA kernels
+    land; both sides use the same bf16 operands, so the numerics of the training step do not change."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w16, stride, padding, want_stats):
+        ctx.stride, ctx.padding = stride, padding
+        if want_stats:
+            y, stats = conv2d_igemm(x, w16, stride, padding, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+        else:
+            y, stats = conv2d_igemm(x, w16, stride, padding), None
+        ctx.save_for_backward(x, w16)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, w16 = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        need_dx = ctx.needs_input_grad[0]
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
+            [need_dx, True, False])
+        return dx, dw.float(), None, None, None, None
+
+
+# Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
+# WITHOUT bumping Tensor._version (measured: torch 2.10 fused Adam leaves _version untouched), so the bf16 weight
+# cache is keyed on (generation, _version, data_ptr) and every optimizer.step() anywhere bumps the generation.
+_GENERATION = [0]
+
+
+def invalidate_weight_cache(*_a, **_k):
+    _GENERATION[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook  # noqa: E402
+_reg_post_hook(invalidate_weight_cache)
+
+
+def conv_bn_input(x, conv, want_stats):
+    """Apply ``conv`` (an ``nn.Conv2d`` with bias=False, Cin/Cout multiples of 64) to a bf16 channels_last tensor with
+    the MFMA kernel. Returns ``(y, partial_stats or None)``. The bf16 copy of the fp32 master weight is cached until
+    the next optimizer step / in-place edit (one cast per step instead of one per use: train forward, epoch-tail
+    forward and the backward share it)."""
+    w = conv.weight
+    key = (_GENERATION[0], w._version, w.data_ptr())
+    cache = getattr(conv, "_dir_w16", None)
+    if cache is None or cache[0] != key:
+        w16 = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        conv._dir_w16 = (key, w16)
+    else:
+        w16 = cache[1]
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return _ConvFn.apply(x, w, w16, conv.stride[0], conv.padding[0], want_stats)

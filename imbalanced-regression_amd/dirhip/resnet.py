@@ -18,9 +18,20 @@ import torch
 import torch.nn as nn
 
 from .bn import bn_act
+from .conv import conv_bn_input, supported as _igemm_ok
 from .fds import FDS
 
 print = logging.info
+
+
+def _conv_bn(x, conv, bn, relu, residual=None):
+    """conv -> BatchNorm (+ residual) (+ ReLU). bf16 activations: hand-written MFMA implicit-GEMM convolution whose
+    epilogue already produced the BatchNorm statistics, then ONE fused normalise/add/ReLU pass. fp32 activations
+    (parity mode): library convolution + the fused HIP BatchNorm node."""
+    if x.dtype == torch.bfloat16 and _igemm_ok(conv.in_channels, conv.out_channels):
+        y, partial = conv_bn_input(x, conv, want_stats=bn.training)
+        return bn_act(y, bn, relu=relu, residual=residual, partial=partial)
+    return bn_act(conv(x), bn, relu=relu, residual=residual)
 
 
 class Bottleneck(nn.Module):
@@ -41,10 +52,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        y = bn_act(self.conv1(x), self.bn1, relu=True)
-        y = bn_act(self.conv2(y), self.bn2, relu=True)
-        return bn_act(self.conv3(y), self.bn3, relu=True, residual=shortcut)      # relu(bn3(.) + shortcut)
+        shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
+        y = _conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = _conv_bn(y, self.conv2, self.bn2, relu=True)
+        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut)    # relu(bn3(conv3(.)) + shortcut)
 
 
 class ResNet(nn.Module):

@@ -201,6 +201,13 @@ int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, in
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      double momentum, double eps, int relu, float* save_mean, float* save_rstd,
                      void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* same as dir_bn_fwd_train, but the per-channel (sum, sum of squares) partials [partial_rows][2][C] f32 were already
+ * produced by dir_conv_fwd's epilogue: no statistics pass over x. */
+int dir_bn_fwd_train_partials(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
+                              const float* partial, int partial_rows,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              double momentum, double eps, int relu, float* save_mean, float* save_rstd,
+                              void* workspace, size_t workspace_bytes, dir_stream_t stream);
 int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                     const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                     double eps, int relu, void* workspace, size_t workspace_bytes, dir_stream_t stream);
@@ -208,6 +215,21 @@ int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void*
                int64_t M, int C, const float* gamma, const float* save_mean, const float* save_rstd,
                float* dgamma, float* dbeta, int relu, void* workspace, size_t workspace_bytes,
                dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9  convolution as MFMA implicit GEMM, NHWC bf16, fp32 accumulation.  Replaces nn.Conv2d (bias=False) of
+ * imdb-wiki-dir/resnet.py:44-49,79,114-115 for every layer with Cin % 64 == 0 and Cout % 64 == 0 (all but the stem).
+ *   x [N, H, W, Cin] bf16;  w [Cout, R, S, Cin] bf16 (= a channels_last [Cout, Cin, R, S] tensor);
+ *   y [N, Ho, Wo, Cout] bf16,  Ho = (H + 2 pad - R) / stride + 1.
+ *   stats (optional, may be NULL): [dir_conv_stats_rows(N, Ho, Wo)][2][Cout] f32 — per 128-row tile, the sum and the
+ *   sum of squares of the (bf16-rounded) outputs of each channel: the partial-sum buffer dir_bn_* consumes, so the
+ *   BatchNorm that follows needs no statistics pass of its own.
+ * The same entry point computes the data gradient of a stride-1 convolution when given dY and the 180-degree
+ * rotated, in/out-transposed weights.
+ */
+size_t dir_conv_stats_rows(int N, int Ho, int Wo);
+int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
+                 int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""-m gpu: MFMA implicit-GEMM convolution (dir_conv_fwd) vs a plain PyTorch fp32 reference of the same op
+(F.conv2d in float32 on the bf16-rounded inputs), including borders, strides, ragged M tails, and the fused
+BatchNorm partial statistics."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (N, Cin, H, W, Cout, k, stride, pad)
+    (2, 64, 56, 56, 64, 1, 1, 0), (2, 64, 56, 56, 256, 1, 1, 0), (3, 256, 28, 28, 128, 1, 1, 0),
+    (2, 256, 56, 56, 512, 1, 2, 0), (1, 1024, 14, 14, 2048, 1, 2, 0), (5, 2048, 7, 7, 512, 1, 1, 0),
+    (2, 64, 56, 56, 64, 3, 1, 1), (2, 128, 56, 56, 128, 3, 2, 1), (3, 256, 14, 14, 256, 3, 1, 1),
+    (2, 512, 7, 7, 512, 3, 1, 1), (1, 64, 9, 13, 192, 3, 1, 1), (7, 128, 5, 3, 64, 3, 2, 1), (1, 64, 1, 1, 64, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_igemm_matches_fp32_reference(case):
+    from dirhip.conv import conv2d_igemm
+    n, cin, h, w, cout, k, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    # asymmetric weights (distinct per (co, ci, r, s)) so any operand transposition shows up
+    wt = (torch.randn(cout, cin, k, k, device="cuda", generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(torch.bfloat16)
+    wt = wt.contiguous(memory_format=torch.channels_last)
+    y, stats = conv2d_igemm(x, wt, stride, pad, want_stats=True)
+    ref = F.conv2d(x.float(), wt.float(), None, stride, pad)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    # bf16 output rounding: 2^-9 relative of the element + fp32 accumulation-order noise relative to the scale
+    assert_close(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=4e-3, atol_scale=2e-3, msg=str(case))
+    # fused statistics = sums over the rounded outputs
+    yr = y.float().permute(0, 2, 3, 1).reshape(-1, cout).double()
+    s = stats.double().sum(0).cpu().numpy()
+    assert_close(s[0], yr.sum(0).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sum")
+    assert_close(s[1], (yr * yr).sum(0).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sumsq")
+
+
+def test_conv_igemm_identity_weights_asymmetric_input():
+    """A = I check with an asymmetric input: the output must be the input, bit for bit (1x1, identity weights)."""
+    from dirhip.conv import conv2d_igemm
+    c = 128
+    x = torch.arange(2 * c * 6 * 5, device="cuda").float().reshape(2, 6, 5, c).permute(0, 3, 1, 2) % 251
+    x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.eye(c, device="cuda").reshape(c, c, 1, 1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = conv2d_igemm(x, w)
+    assert torch.equal(y, x)
+
+
+def test_conv_stats_feed_fused_batchnorm():
+    """conv (MFMA) -> BatchNorm with the statistics taken from the conv epilogue == the same BatchNorm computing its
+    own statistics from y, and == the fp32 reference chain; gradients flow through the custom conv node."""
+    import torch.nn as nn
+    from dirhip.bn import bn_act
+    from dirhip.conv import conv_bn_input
+    g = torch.Generator(device="cuda").manual_seed(5)
+    conv = nn.Conv2d(128, 256, 3, 1, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(256).cuda(), nn.BatchNorm2d(256).cuda()
+    x = torch.randn(6, 128, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y, partial = conv_bn_input(x, conv, want_stats=True)
+    assert partial is not None and partial.shape[1:] == (2, 256)
+    out_a = bn_act(y, bn_a, relu=True, partial=partial)
+    with torch.no_grad():
+        out_b = bn_act(y.detach(), bn_b, relu=True)
+    assert_close(out_a.float().detach().cpu().numpy(), out_b.float().cpu().numpy(), rtol=1e-2, atol_scale=4e-3)
+    assert_close(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol_scale=1e-6)
+    assert_close(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol_scale=1e-6)
+    dy = torch.randn(out_a.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out_a.backward(dy)
+    # fp32 reference chain on the same bf16-rounded operands
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    outr = torch.relu(F.batch_norm(yr, None, None, torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"), True, 0.1, 1e-5))
+    outr.backward(dy.float())
+    assert_close(out_a.float().detach().cpu().numpy(), outr.detach().cpu().numpy(), rtol=2e-2, atol_scale=1e-2, msg="out")
+    # gradients pass through bf16 storage and a ReLU mask taken from bf16-rounded activations: a handful of
+    # elements near the ReLU kink flip, so the check is norm-wise (relative L2 error) plus an outlier budget
+    def l2(a, b):
+        return float((a - b).norm() / b.norm())
+    assert l2(x.grad.float(), xr.grad) < 2e-2, l2(x.grad.float(), xr.grad)
+    assert l2(conv.weight.grad, wr.grad) < 2e-2, l2(conv.weight.grad, wr.grad)
+    bad = ((x.grad.float() - xr.grad).abs() > 5e-2 * xr.grad.abs() + 2e-2 * xr.grad.abs().max()).float().mean().item()
+    assert bad < 5e-3, bad
+    assert conv.weight.grad.dtype == torch.float32
+
+
+def test_weight_cache_follows_fused_optimizer_steps():
+    """torch's fused Adam does not bump Tensor._version; the bf16 weight cache must still refresh after step()."""
+    import torch.nn as nn
+    from dirhip.conv import conv_bn_input
+    conv = nn.Conv2d(64, 64, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    opt = torch.optim.Adam(conv.parameters(), lr=0.1, fused=True)
+    x = torch.randn(2, 64, 8, 8, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y0, _ = conv_bn_input(x, conv, False)
+    y0.float().sum().backward()
+    opt.step()
+    y1, _ = conv_bn_input(x, conv, False)
+    ref = F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float())
+    assert not torch.equal(y0, y1)
+    assert_close(y1.float().detach().cpu().numpy(), ref.cpu().numpy(), rtol=4e-3, atol_scale=2e-3)
