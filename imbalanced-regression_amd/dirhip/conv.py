@@ -42,27 +42,33 @@ class _ConvFn(torch.autograd.Function):
     land; both sides use the same bf16 operands, so the numerics of the training step do not change."""
 
     @staticmethod
-    def forward(ctx, x, weight, w16, stride, padding, want_stats):
+    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats):
         ctx.stride, ctx.padding = stride, padding
         if want_stats:
             y, stats = conv2d_igemm(x, w16, stride, padding, want_stats=True)
             ctx.mark_non_differentiable(stats)
         else:
             y, stats = conv2d_igemm(x, w16, stride, padding), None
-        ctx.save_for_backward(x, w16)
+        ctx.save_for_backward(x, w16, w16_rot)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        x, w16 = ctx.saved_tensors
+        x, w16, w16_rot = ctx.saved_tensors
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         need_dx = ctx.needs_input_grad[0]
-        dx, dw, _ = torch.ops.aten.convolution_backward(
+        dx = None
+        if need_dx and w16_rot is not None:
+            # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
+            # in/out-transposed weights and padding R-1-pad
+            dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding)
+            need_dx = False
+        dxl, dw, _ = torch.ops.aten.convolution_backward(
             dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
             [need_dx, True, False])
-        return dx, dw.float(), None, None, None, None
+        return (dx if dx is not None else dxl), dw.float(), None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -89,9 +95,13 @@ def conv_bn_input(x, conv, want_stats):
     cache = getattr(conv, "_dir_w16", None)
     if cache is None or cache[0] != key:
         w16 = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        conv._dir_w16 = (key, w16)
+        w16_rot = None
+        if conv.stride[0] == 1 and supported(conv.out_channels, conv.in_channels):
+            # [Cin][R][S][Cout] with the taps rotated by 180 degrees: the weight of the data-gradient convolution
+            w16_rot = w16.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        conv._dir_w16 = (key, w16, w16_rot)
     else:
-        w16 = cache[1]
+        w16, w16_rot = cache[1], cache[2]
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
-    return _ConvFn.apply(x, w, w16, conv.stride[0], conv.padding[0], want_stats)
+    return _ConvFn.apply(x, w, w16, w16_rot if torch.is_grad_enabled() else None, conv.stride[0], conv.padding[0], want_stats)

@@ -271,21 +271,26 @@ def gen_train_trajectory():
     out = {}
     # ---- (a) config 1
     rows = np.random.default_rng(0).choice(len(ages), 8, replace=False)
-    torch.manual_seed(11)
-    model = refshim.make_resnet50("agedb-dir", fds=False, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1,
-                                  kernel="gaussian", ks=9, sigma=1, momentum=0.9)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(0))
     y = torch.tensor(ages[rows], dtype=torch.float32).view(-1, 1)
     w = torch.tensor(w_all[rows]).view(-1, 1)
-    losses = []
-    model.train()
-    for _ in range(4):
-        o = model(x, y, 0)
-        loss = ref.loss.weighted_l1_loss(o, y, w)
-        opt.zero_grad(); loss.backward(); opt.step()
-        losses.append(loss.item())
-    out.update(a_rows=rows, a_labels=y.numpy(), a_weights=w.numpy(), a_ref_losses=np.array(losses))
+
+    def run_a(noise):
+        torch.manual_seed(11)
+        model = refshim.make_resnet50("agedb-dir", fds=False, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1,
+                                      kernel="gaussian", ks=9, sigma=1, momentum=0.9)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+        if noise:
+            x = x * (1 + noise * torch.randn(x.shape, generator=torch.Generator().manual_seed(5)))
+        losses = []
+        model.train()
+        for _ in range(4):
+            o = model(x, y, 0)
+            loss = ref.loss.weighted_l1_loss(o, y, w)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+        return np.array(losses)
+    out.update(a_rows=rows, a_labels=y.numpy(), a_weights=w.numpy(), a_ref_losses=run_a(0.0), a_pert_losses=run_a(1e-6))
     # ---- (b) LDS + FDS, run twice: exact inputs and inputs perturbed by 1e-6 relative noise. ResNet-50 + BN at
     # B=6 is chaotic (the second run diverges from the first by ~1e-4 after one step and ~1e-2 after five), so the
     # perturbed run is the yardstick for what "the same trajectory" can mean across two conv libraries.
