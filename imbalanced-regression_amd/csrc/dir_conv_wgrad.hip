@@ -1,0 +1,291 @@
+// Weight gradient of the NHWC bf16 convolution as an MFMA GEMM with the batch*pixel axis as K (gfx950).
+//
+//   dW[co, r, s, ci] = sum_{m = (n, ho, wo)} dY[m, co] * X[n, ho*stride - pad + r, wo*stride - pad + s, ci]
+//
+// Replaces the weight-gradient half of the autograd of nn.Conv2d in imdb-wiki-dir/resnet.py (cuDNN in the
+// reference; MIOpen's atomic split-K kernels + zero-fill + cast passes in round 1 of this repo).
+//
+// GEMM view per filter tap: D[co][ci] (TM x TN tile) with K = M = N*Ho*Wo. BOTH operands are stored with K as the
+// SLOW axis (rows m, channels contiguous), while an MFMA lane needs 8 consecutive k of one row. So the global ->
+// LDS staging transposes on the fly: a thread fetches the same 16-byte channel group (8 channels) of 4
+// consecutive rows m, permutes the 4x8 block in registers (v_perm_b32) into 8 x (4 consecutive k) and issues
+// eight 8-byte ds_write_b64 into a [channel][k] tile — after that the tiles look exactly like the forward
+// kernel's ([row][64 k], 128-byte rows, 16-byte chunks XOR-swizzled) and the fragment reads are plain
+// ds_read_b128. Swizzle f(row) = ((row >> 1) ^ (row >> 4)) & 7: conflict-free fragment reads, 2-way on the
+// transposing writes (the minimum for 16 lanes x 8 B landing on 8 chunk slots).
+// Split-K: K is cut into `splits` contiguous ranges (one workgroup each, per tile and tap); partial tiles go to
+// a float32 workspace [split][Cout][R*S][Cin] and are summed in split order by a second kernel: deterministic,
+// no atomics, no zero-fill pass.
+#include "dir_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
+
+struct WgP {
+    const uint16_t* dy; const uint16_t* x; float* part;
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+    int M, RS, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split;
+    float inv_wo, inv_ho;
+    int simple;               // 1x1, stride 1, pad 0: gathered row == m
+};
+
+constexpr int WG_BK = 64, WG_ROWB = 128;
+
+__device__ __forceinline__ u32x4 wg_gload(const uint16_t* base, ptrdiff_t off) {
+    return *reinterpret_cast<gvec_ptr>(reinterpret_cast<uintptr_t>(base + off));
+}
+__device__ __forceinline__ int wg_swz(int row, int chunk) { return chunk ^ (((row >> 1) ^ (row >> 4)) & 7); }
+
+// Row m = (n, ho, wo) of the implicit im2col matrix for filter tap (tr, ts): 16 B of X or zeros outside the image.
+// Integer divisions by Wo / Ho are a float multiply plus one correction step (exact for m < 2^24).
+__device__ __forceinline__ u32x4 wg_gather(const WgP& p, int mm, int tr, int ts, int coff) {
+    int q1 = (int)((float)mm * p.inv_wo); int wo = mm - q1 * p.Wo;
+    if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+    int n = (int)((float)q1 * p.inv_ho); int ho = q1 - n * p.Ho;
+    if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+    const int hi = ho * p.stride - p.pad + tr, wi = wo * p.stride - p.pad + ts;
+    const bool ok = mm < p.M && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+    const ptrdiff_t o = ok ? ((ptrdiff_t)((n * p.H + hi) * p.W + wi) * p.Cin + coff) : 0;
+    const u32x4 v = wg_gload(p.x, o);
+    const uint32_t k = ok ? ~0u : 0u;
+    return v & k;
+}
+
+// 4 rows x 8 channels (4 x 16 B) -> 8 channels x 4 k, written as 8-byte pieces into the [channel][k] tile.
+__device__ __forceinline__ void wg_transpose_store(unsigned char* tile, int ch0, int rg, const u32x4& r0, const u32x4& r1,
+                                                   const u32x4& r2, const u32x4& r3) {
+    const int chunk = rg >> 1, half = (rg & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // v_perm_b32(src0 = high dword, src1 = low dword): 0x05040100 -> lo16(src1) | lo16(src0) << 16
+        const uint32_t lo01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x05040100u), lo23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x05040100u);
+        const uint32_t hi01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x07060302u), hi23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x07060302u);
+        const int row_lo = ch0 + 2 * q, row_hi = row_lo + 1;
+        *reinterpret_cast<uint2*>(tile + row_lo * WG_ROWB + (wg_swz(row_lo, chunk) << 4) + half) = make_uint2(lo01, lo23);
+        *reinterpret_cast<uint2*>(tile + row_hi * WG_ROWB + (wg_swz(row_hi, chunk) << 4) + half) = make_uint2(hi01, hi23);
+    }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(DIR_TPB)
+conv_wgrad_kernel(WgP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_BYTES = TM * WG_ROWB, B_BYTES = TN * WG_ROWB;
+    constexpr int MI = TM / 64, NI = TN / 64;                     // 32x32 MFMA tiles per wavefront (2x2 wavefronts)
+    constexpr int CA = TM / 8, CB = TN / 8;                       // 16-B chunk columns of the global tiles
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * A_BYTES;
+
+    // Workgroup order: filter tap fastest, then ci tile, co tile, K range — workgroups that re-read the same dY rows
+    // (all taps / ci tiles of one (co tile, K range)) and overlapping X rows (neighbouring taps) are adjacent, and
+    // the XCD remap keeps adjacent ids on one XCD so those re-reads hit that XCD's L2.
+    int b;
+    {
+        const int nb = gridDim.x, id = blockIdx.x, q = nb / 8, r = nb % 8, xcd = id % 8, i = id / 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int tap = b % p.RS; b /= p.RS;
+    const int tn = b % p.tiles_n; b /= p.tiles_n;
+    const int tm = b % p.tiles_m; b /= p.tiles_m;
+    const int split = b;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int co0 = tm * TM, ci0 = tn * TN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+
+    const int ks0 = split * p.ksteps_per_split;
+    int ks1 = ks0 + p.ksteps_per_split; if (ks1 > p.ksteps_total) ks1 = p.ksteps_total;
+
+    // loader roles: A chunk column ca / row group ga (threads < 2*TM), B chunk column cb / row group gb (threads < 2*TN)
+    const bool doA = t < 2 * TM, doB = t < 2 * TN;
+    const int ca = t % CA, ga = t / CA, cb = t % CB, gb = t / CB;
+
+    u32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+#define WG_LOAD(ks)                                                                                               \
+    {                                                                                                             \
+        const int mbase = (ks) * WG_BK;                                                                           \
+        if (doA) {                                                                                                \
+            const int m = mbase + 4 * ga;                                                                         \
+            const ptrdiff_t o = (ptrdiff_t)m * p.Cout + co0 + ca * 8;                                             \
+            a0 = (m + 0 < p.M) ? wg_gload(p.dy, o) : zero;                                                        \
+            a1 = (m + 1 < p.M) ? wg_gload(p.dy, o + p.Cout) : zero;                                               \
+            a2 = (m + 2 < p.M) ? wg_gload(p.dy, o + 2 * (ptrdiff_t)p.Cout) : zero;                                \
+            a3 = (m + 3 < p.M) ? wg_gload(p.dy, o + 3 * (ptrdiff_t)p.Cout) : zero;                                \
+        }                                                                                                         \
+        if (doB) {                                                                                                \
+            const int m = mbase + 4 * gb;                                                                         \
+            if (p.simple) {                                                                                       \
+                const ptrdiff_t o = (ptrdiff_t)m * p.Cin + ci0 + cb * 8;                                          \
+                b0 = (m + 0 < p.M) ? wg_gload(p.x, o) : zero;                                                     \
+                b1 = (m + 1 < p.M) ? wg_gload(p.x, o + p.Cin) : zero;                                             \
+                b2 = (m + 2 < p.M) ? wg_gload(p.x, o + 2 * (ptrdiff_t)p.Cin) : zero;                              \
+                b3 = (m + 3 < p.M) ? wg_gload(p.x, o + 3 * (ptrdiff_t)p.Cin) : zero;                              \
+            } else {                                                                                              \
+                b0 = wg_gather(p, m + 0, tr, ts, ci0 + cb * 8); b1 = wg_gather(p, m + 1, tr, ts, ci0 + cb * 8);       \
+                b2 = wg_gather(p, m + 2, tr, ts, ci0 + cb * 8); b3 = wg_gather(p, m + 3, tr, ts, ci0 + cb * 8);       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+#define WG_STORE(buf)                                                                                             \
+    {                                                                                                             \
+        if (doA) wg_transpose_store(As + (buf) * A_BYTES, ca * 8, ga, a0, a1, a2, a3);                            \
+        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, cb * 8, gb, b0, b1, b2, b3);                            \
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    if (ks0 < ks1) {
+        WG_LOAD(ks0);
+        WG_STORE(0);
+        __syncthreads();
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int buf = (ks - ks0) & 1;
+            const bool more = ks + 1 < ks1;
+            if (more) WG_LOAD(ks + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[MI], bb[NI];
+                const int chunk = kk * 2 + fhalf;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = wm * (TM / 2) + mi * 32 + frow;
+                    a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * WG_ROWB + (wg_swz(row, chunk) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = wn * (TN / 2) + ni * 32 + frow;
+                    bb[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * WG_ROWB + (wg_swz(row, chunk) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) WG_STORE(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#undef WG_LOAD
+#undef WG_STORE
+
+    // partial[split][co][tap][ci] (fp32). C/D: col = lane & 31 -> ci, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -> co.
+    float* out = p.part + (size_t)split * p.Cout * p.RS * p.Cin;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * (TM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                const int ci = ci0 + wn * (TN / 2) + ni * 32 + frow;
+                out[((size_t)co * p.RS + tap) * p.Cin + ci] = acc[mi][ni][e];
+            }
+}
+
+// Sum the split partials in split order. 256 threads = 16 float4 columns x 16 split lanes: lane j adds splits
+// j, j+16, ... (independent loads in flight), then the 16 lane sums are added in lane order through LDS —
+// a fixed summation tree, so the result is bit-reproducible, and a 1024-way split costs 64 loads per thread
+// instead of a 1024-long dependent chain.
+constexpr int RD_COLS = 16, RD_LANES = DIR_TPB / RD_COLS;
+__global__ void __launch_bounds__(DIR_TPB)
+conv_wgrad_reduce_kernel(const float* __restrict__ part, int splits, size_t n, float* __restrict__ dw) {
+    __shared__ float4 sh[RD_LANES][RD_COLS];
+    const int col = threadIdx.x % RD_COLS, sl = threadIdx.x / RD_COLS;
+    const size_t i = ((size_t)blockIdx.x * RD_COLS + col) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += RD_LANES) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float4 t = sh[0][col];
+#pragma unroll
+        for (int k = 1; k < RD_LANES; ++k) { const float4 v = sh[k][col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(dw + i) = t;
+    }
+}
+
+struct WgPlan { int tm, tn, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split; size_t ws_bytes; };
+
+WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
+    WgPlan pl;
+    pl.tm = (Cout % 128 == 0) ? 128 : 64;
+    pl.tn = (Cin % 128 == 0) ? 128 : 64;
+    pl.tiles_m = Cout / pl.tm; pl.tiles_n = Cin / pl.tn;
+    pl.ksteps_total = (int)((M + WG_BK - 1) / WG_BK);
+    const int tiles = pl.tiles_m * pl.tiles_n * RS;
+    int splits = (1024 + tiles - 1) / tiles;                     // aim at ~1024 workgroups (2 per CU, 2 rounds)
+    int max_splits = pl.ksteps_total / 4; if (max_splits < 1) max_splits = 1;      // >= 4 K-steps per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    pl.ksteps_per_split = (pl.ksteps_total + splits - 1) / splits;
+    pl.splits = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+    pl.ws_bytes = dir_align_up(sizeof(float) * (size_t)pl.splits * Cout * RS * Cin, 256);
+    return pl;
+}
+
+template <int TM, int TN>
+void wg_launch(const WgP& p, int nblocks, hipStream_t s) {
+    constexpr int lds = 2 * (TM + TN) * WG_ROWB;
+    hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN>), dim3(nblocks), dim3(DIR_TPB), lds, s, p);
+}
+
+}  // namespace
+
+extern "C" size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    return wg_plan((long long)N * Ho * Wo, Cin, Cout, R * S).ws_bytes;
+}
+
+extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                              int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
+                              dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !x || !dw || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
+    DIR_RETURN_IF(Cin % 64 != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || !dir_aligned16(dw) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
+    const long long M = (long long)N * Ho * Wo;
+    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31), DIR_EUNSUPPORTED);
+    const WgPlan pl = wg_plan(M, Cin, Cout, R * S);
+    DIR_RETURN_IF(workspace_bytes < pl.ws_bytes, DIR_EWORKSPACE);
+    WgP p;
+    p.dy = static_cast<const uint16_t*>(dy); p.x = static_cast<const uint16_t*>(x); p.part = static_cast<float*>(workspace);
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.RS = R * S; p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits;
+    p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
+    p.inv_wo = 1.0f / (float)Wo; p.inv_ho = 1.0f / (float)Ho;
+    p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    const int nblocks = pl.splits * pl.tiles_m * pl.tiles_n * p.RS;
+    hipStream_t s = dir_s(stream);
+    if (pl.tm == 128 && pl.tn == 128) wg_launch<128, 128>(p, nblocks, s);
+    else if (pl.tm == 128) wg_launch<128, 64>(p, nblocks, s);
+    else if (pl.tn == 128) wg_launch<64, 128>(p, nblocks, s);
+    else wg_launch<64, 64>(p, nblocks, s);
+    DIR_LAUNCH_CHECK();
+    const size_t n = (size_t)Cout * p.RS * Cin;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(dir_cdiv((long long)n / 4, RD_COLS)), dim3(DIR_TPB), 0, s, p.part, pl.splits, n, dw);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

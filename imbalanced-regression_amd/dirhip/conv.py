@@ -36,10 +36,30 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False):
     return (y, stats) if want_stats else y
 
 
+def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
+    """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``."""
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+    if not dy.is_contiguous(memory_format=torch.channels_last):
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    r = s = kernel_size
+    nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding)
+    if nbytes == 0:
+        raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, L.ptr(ws),
+                                   ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
+    return dw
+
+
 class _ConvFn(torch.autograd.Function):
-    """Forward = hand-written MFMA implicit GEMM (+ BatchNorm partial statistics in the epilogue). Backward (data and
-    weight gradients) still goes to the library convolution-backward kernels until the dgrad / wgrad MFMA kernels
-    land; both sides use the same bf16 operands, so the numerics of the training step do not change."""
+    """Forward = hand-written MFMA implicit GEMM (+ BatchNorm partial statistics in the epilogue); data gradient of
+    stride-1 layers = the same kernel on dY with rotated/transposed weights; weight gradient = the MFMA split-K
+    kernel ``dir_conv_wgrad``. Only the data gradient of the six stride-2 layers still uses the library kernel."""
 
     @staticmethod
     def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats):
@@ -65,10 +85,12 @@ class _ConvFn(torch.autograd.Function):
             # in/out-transposed weights and padding R-1-pad
             dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding)
             need_dx = False
-        dxl, dw, _ = torch.ops.aten.convolution_backward(
-            dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
-            [need_dx, True, False])
-        return (dx if dx is not None else dxl), dw.float(), None, None, None, None, None
+        dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
+        if need_dx:                                                              # strided data gradient: library kernel for now
+            dx = torch.ops.aten.convolution_backward(
+                dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
+                [True, False, False])[0]
+        return dx, dw, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters

@@ -231,6 +231,17 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
 int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 
+/* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
+ * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the
+ * batch*pixel axis as K, operands transposed in registers on their way into LDS, deterministic split-K through
+ * `workspace` (>= dir_conv_wgrad_workspace(...) bytes, 256-byte aligned; 0 = unsupported shape).
+ * Replaces the weight half of nn.Conv2d's autograd (imdb-wiki-dir/resnet.py conv layers with Cin, Cout % 64 == 0).
+ */
+size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                   int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
+                   dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,3 +29,21 @@ for cin,cout,k,st,h,cnt in SH:
     tot_o+=to*cnt; tot_t+=tt*cnt
     print(f"{cin:5d}->{cout:5d} k{k} s{st} H{h:3d} x{cnt} | ours {to*1e3:8.1f}us {fl/to/1e9:7.1f}TF {byt/to/1e6:6.0f}GB/s | miopen {tt*1e3:8.1f}us {fl/tt/1e9:7.1f}TF | x{tt/to:5.2f} maxdiff {err:.3g}",flush=True)
 print(f"TOTAL fwd per pass: ours {tot_o:.2f} ms  miopen {tot_t:.2f} ms")
+print("---- weight gradient")
+from dirhip.conv import conv2d_wgrad
+tot_o=tot_t=0
+for cin,cout,k,st,h,cnt in SH:
+    pad=k//2
+    x=torch.randn(B,cin,h,h,device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w=(torch.randn(cout,cin,k,k,device='cuda')*0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ho=(h+2*pad-k)//st+1
+    dy=torch.randn(B,cout,ho,ho,device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    fl=2.0*B*ho*ho*cout*cin*k*k
+    to=ev(lambda: conv2d_wgrad(dy,x,k,st,pad))
+    tt=ev(lambda: torch.ops.aten.convolution_backward(dy,x,w,None,[st,st],[pad,pad],[1,1],False,[0,0],1,[False,True,False]))
+    ref=torch.ops.aten.convolution_backward(dy,x,w,None,[st,st],[pad,pad],[1,1],False,[0,0],1,[False,True,False])[1].float()
+    mine=conv2d_wgrad(dy,x,k,st,pad)
+    err=((mine-ref).abs().max()/ref.abs().max()).item()
+    tot_o+=to*cnt; tot_t+=tt*cnt
+    print(f"{cin:5d}->{cout:5d} k{k} s{st} H{h:3d} x{cnt} | ours {to*1e3:8.1f}us {fl/to/1e9:7.1f}TF | miopen {tt*1e3:8.1f}us {fl/tt/1e9:7.1f}TF | x{tt/to:5.2f} relerr {err:.2g}",flush=True)
+print(f"TOTAL wgrad per pass: ours {tot_o:.2f} ms  miopen {tot_t:.2f} ms")
