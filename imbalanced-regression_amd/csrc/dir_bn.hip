@@ -168,14 +168,14 @@ bn_finalize_train_kernel(const float* __restrict__ partial, int rblocks, int64_t
     const double rstd = 1.0 / sqrt(var + eps);
     save_mean[c] = (float)mean;
     save_rstd[c] = (float)rstd;
+    const double meanf = (double)(float)mean, rstdf = (double)(float)rstd;   // what the backward will see
     if (running_mean) {                                    // torch: running = (1-m)*running + m*batch, unbiased var
         const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
-    const float a = (float)((double)gamma[c] * rstd);
-    coef[c] = a;
-    coef[C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    coef[c] = (float)((double)gamma[c] * rstdf);
+    coef[C + c] = (float)((double)beta[c] - meanf * (double)gamma[c] * rstdf);
 }
 
 __global__ void __launch_bounds__(DIR_TPB)
@@ -239,13 +239,29 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
 }
 
 // ---- backward: g = dout * [out > 0];  partial sums of g and g * x ------------------------------------------
-template <typename T, bool RELU>
+// ReLU mask source: 0 = no ReLU, 1 = saved output (needed when a residual was added), 2 = recomputed from x with
+// the forward's own coefficients (x*a+b > 0; bit-identical to the forward's decision, one tensor read less).
+struct BnMaskCoef { const float* gamma; const float* beta; const float* mean; const float* rstd; };
+template <int VEC>
+__device__ __forceinline__ void bn_mask_coef(const BnMaskCoef& mc, int c, float (&af)[VEC], float (&bf)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const double gm = (double)mc.gamma[c + j], rs = (double)mc.rstd[c + j];
+        af[j] = (float)(gm * rs);
+        bf[j] = (float)((double)mc.beta[c + j] - (double)mc.mean[c + j] * gm * rs);
+    }
+}
+
+template <typename T, int MASK>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ out,
-                      int64_t M, int C, BnGeom g, float* __restrict__ partial) {
+                      int64_t M, int C, BnGeom g, float* __restrict__ partial, BnMaskCoef mc) {
     constexpr int VEC = Vec<T>::N;
+    constexpr bool RELU = (MASK == 1);
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
     const int c0 = blockIdx.y * g.ct, c = c0 + tg * VEC;
+    float af[VEC], bf[VEC];
+    if (MASK == 2) bn_mask_coef<VEC>(mc, c, af, bf);
     float acc[2][VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
@@ -263,7 +279,8 @@ bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                if (MASK == 2 && !(v[u][j] * af[j] + bf[j] > 0.0f)) gj = 0.0f;
                 acc[0][j] += gj; acc[1][j] += gj * v[u][j];
             }
     }
@@ -274,7 +291,8 @@ bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const
         if (RELU) Vec<T>::load(out + row * C + c, o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            if (MASK == 2 && !(v[j] * af[j] + bf[j] > 0.0f)) gj = 0.0f;
             acc[0][j] += gj; acc[1][j] += gj * v[j];
         }
     }
@@ -302,13 +320,17 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int rblocks, int64_t M
     coef[2 * C + c] = (float)(-a * sg / n - p * mean);
 }
 
-template <typename T, bool RELU, bool DRES>
+template <typename T, int MASK, bool DRES>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ out,
-                    T* __restrict__ dx, T* __restrict__ dres, int64_t M, int C, BnGeom g, const float* __restrict__ coef) {
+                    T* __restrict__ dx, T* __restrict__ dres, int64_t M, int C, BnGeom g, const float* __restrict__ coef,
+                    BnMaskCoef mc) {
     constexpr int VEC = Vec<T>::N;
+    constexpr bool RELU = (MASK == 1);
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
     const int c = blockIdx.y * g.ct + tg * VEC;
+    float af[VEC], bf[VEC];
+    if (MASK == 2) bn_mask_coef<VEC>(mc, c, af, bf);
     float a[VEC], p[VEC], q[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; p[j] = coef[C + c + j]; q[j] = coef[2 * C + c + j]; }
@@ -328,7 +350,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
             const int64_t pr = M - 1 - (row + u * stride);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                float gj = (RELU && !(o[u][j] > 0.0f)) ? 0.0f : d[u][j];
+                if (MASK == 2 && !(v[u][j] * af[j] + bf[j] > 0.0f)) gj = 0.0f;
                 d[u][j] = gj;
                 v[u][j] = a[j] * gj + (p[j] * v[u][j] + q[j]);
             }
@@ -344,7 +367,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
         if (RELU) Vec<T>::load(out + pr * C + c, o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            float gj = (RELU && !(o[j] > 0.0f)) ? 0.0f : d[j];
+            if (MASK == 2 && !(v[j] * af[j] + bf[j] > 0.0f)) gj = 0.0f;
             d[j] = gj;
             v[j] = a[j] * gj + (p[j] * v[j] + q[j]);
         }
@@ -407,8 +431,8 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
 
 template <typename T>
 int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, void* dres_, int64_t M, int C,
-             const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int relu,
-             void* ws, size_t ws_bytes, hipStream_t s) {
+             const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, float* dgamma,
+             float* dbeta, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
     constexpr int VEC = Vec<T>::N;
     const T* dout = static_cast<const T*>(dout_); const T* x = static_cast<const T*>(x_); const T* out = static_cast<const T*>(out_);
     T* dx = static_cast<T*>(dx_); T* dres = static_cast<T*>(dres_);
@@ -416,16 +440,21 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     BnWs w = bn_ws<VEC>(ws, M, C);
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
     const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
-    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, true>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial);
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, false>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial);
+    const BnMaskCoef mc{gamma, beta, save_mean, save_rstd};
+    // mask source: saved output if given, else recomputed from x (only valid when no residual was added)
+    const int mask = !relu ? 0 : (out ? 1 : 2);
+    if (mask == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 1>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 2>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 0>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
     DIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dir_cdiv(C, FIN_CH)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
                        save_mean, save_rstd, dgamma, dbeta, w.coef);
     DIR_LAUNCH_CHECK();
-    if (relu && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
-    else if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
-    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef);
+    if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
+    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -486,18 +515,18 @@ extern "C" int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int
 }
 
 extern "C" int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void* dres, int dtype,
-                          int64_t M, int C, const float* gamma, const float* save_mean, const float* save_rstd,
-                          float* dgamma, float* dbeta, int relu, void* workspace, size_t workspace_bytes,
-                          dir_stream_t stream) {
+                          int64_t M, int C, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_rstd, float* dgamma, float* dbeta, int relu, void* workspace,
+                          size_t workspace_bytes, dir_stream_t stream) {
     DIR_RETURN_IF(!dout || !x || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace, DIR_EINVAL);
-    DIR_RETURN_IF(relu && !out, DIR_EINVAL);
+    DIR_RETURN_IF(relu && !out && (!beta || dres), DIR_EINVAL);     // mask recompute needs beta and no residual
     DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(dout) || !dir_aligned16(x) || !dir_aligned16(dx) || (out && !dir_aligned16(out)) ||
                   (dres && !dir_aligned16(dres)), DIR_EINVAL);
     if (dtype == DIR_BF16)
-        return bwd_impl<bf16_t>(dout, x, out, dx, dres, M, C, gamma, save_mean, save_rstd, dgamma, dbeta, relu,
+        return bwd_impl<bf16_t>(dout, x, out, dx, dres, M, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, relu,
                                 workspace, workspace_bytes, dir_s(stream));
-    return bwd_impl<float>(dout, x, out, dx, dres, M, C, gamma, save_mean, save_rstd, dgamma, dbeta, relu,
+    return bwd_impl<float>(dout, x, out, dx, dres, M, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, relu,
                            workspace, workspace_bytes, dir_s(stream));
 }

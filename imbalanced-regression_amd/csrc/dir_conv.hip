@@ -257,3 +257,35 @@ extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats,
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight preparation: one launch per conv layer and optimizer step turns the float32 master weight
+// [Cout][R][S][Cin] into the two bf16 operands the MFMA kernels consume — w16 (same layout, forward / wgrad shape)
+// and, optionally, w16_rot [Cin][R][S][Cout] with the taps rotated by 180 degrees (the data-gradient convolution's
+// weight) — instead of a cast + flip + permute + copy chain of library kernels.
+namespace {
+__global__ void __launch_bounds__(DIR_TPB)
+conv_prep_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, uint16_t* __restrict__ w16,
+                         uint16_t* __restrict__ w16_rot) {
+    const size_t n = (size_t)Cout * RS * Cin;
+    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * DIR_TPB) {
+        const uint16_t h = (uint16_t)cv_f2bf(w[i]);
+        w16[i] = h;
+        if (w16_rot) {
+            const int ci = (int)(i % Cin); const size_t t1 = i / Cin; const int tap = (int)(t1 % RS); const int co = (int)(t1 / RS);
+            w16_rot[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = h;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
+                                     dir_stream_t stream) {
+    DIR_RETURN_IF(!w || !w16 || Cout <= 0 || R <= 0 || S <= 0 || Cin <= 0, DIR_EINVAL);
+    const size_t n = (size_t)Cout * R * S * Cin;
+    int grid = dir_cdiv((long long)n, DIR_TPB); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), w, Cout, R * S, Cin,
+                       static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16_rot));
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

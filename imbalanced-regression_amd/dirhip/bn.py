@@ -55,7 +55,9 @@ class _BNActFn(torch.autograd.Function):
                                                  L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
                                                  int(relu), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), stream),
                         "dir_bn_fwd_train")
-            ctx.save_for_backward(x, gamma, y if relu else None, mean, rstd)
+            # the saved output is only needed as the ReLU mask when a residual was added; otherwise the backward
+            # recomputes the mask from x (one tensor read less per pass)
+            ctx.save_for_backward(x, gamma, beta, y if (relu and residual is not None) else None, mean, rstd)
             ctx.relu = bool(relu)
             ctx.has_res = residual is not None
         else:
@@ -69,7 +71,7 @@ class _BNActFn(torch.autograd.Function):
     def backward(ctx, dout):
         if getattr(ctx, "eval_mode", False):
             raise NotImplementedError("bn_act backward in eval mode is not implemented (the reference never needs it)")
-        x, gamma, y, mean, rstd = ctx.saved_tensors
+        x, gamma, beta, y, mean, rstd = ctx.saved_tensors
         dout = _nhwc(dout)
         if dout.dtype != x.dtype:
             dout = dout.to(x.dtype)
@@ -82,8 +84,8 @@ class _BNActFn(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         ws = _ws(code, m, c, x.device)
         L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
-                                   L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(ctx.relu), L.ptr(ws),
-                                   ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
+                                   L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(ctx.relu),
+                                   L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
@@ -92,10 +94,43 @@ def bn_act(x, bn, relu=True, residual=None, partial=None):
     the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only)."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        counter = getattr(bn, "_dir_step_counter", None)
+        if counter is not None:
+            counter.pending += 1                 # one fused increment for all layers (flush_batch_counters)
+        else:
+            bn.num_batches_tracked.add_(1)
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not implemented")
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
                           partial if training else None)
+
+
+class BatchCounters:
+    """All ``num_batches_tracked`` buffers of a network as views of ONE int64 tensor: 53 one-element add kernels per
+    forward become one. ``link(model)`` re-points the buffers (state_dict keys / values unchanged); ``flush()`` adds
+    the forwards seen since the last flush. Re-link after ``model.to(device)``."""
+
+    def __init__(self):
+        self.flat = None
+        self.pending = 0
+        self.n_layers = 0
+
+    def link(self, model):
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if not bns:
+            return self
+        dev = bns[0].num_batches_tracked.device
+        self.flat = torch.stack([m.num_batches_tracked.detach().to(dev) for m in bns]).contiguous()
+        for i, m in enumerate(bns):
+            m.num_batches_tracked = self.flat[i]
+            m._dir_step_counter = self
+        self.n_layers = len(bns)
+        self.pending = 0
+        return self
+
+    def flush(self):
+        if self.flat is not None and self.pending:
+            self.flat.add_(self.pending // self.n_layers)
+            self.pending = 0

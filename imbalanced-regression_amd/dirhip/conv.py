@@ -116,11 +116,17 @@ def conv_bn_input(x, conv, want_stats):
     key = (_GENERATION[0], w._version, w.data_ptr())
     cache = getattr(conv, "_dir_w16", None)
     if cache is None or cache[0] != key:
-        w16 = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wd = w.detach()
+        if not wd.is_contiguous(memory_format=torch.channels_last):
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        cout, cin, r, s = wd.shape
+        w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=wd.device, memory_format=torch.channels_last)
         w16_rot = None
-        if conv.stride[0] == 1 and supported(conv.out_channels, conv.in_channels):
-            # [Cin][R][S][Cout] with the taps rotated by 180 degrees: the weight of the data-gradient convolution
-            w16_rot = w16.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        if conv.stride[0] == 1 and supported(cout, cin):
+            # [Cin][R][S][Cout], taps rotated by 180 degrees: the weight of the data-gradient convolution
+            w16_rot = torch.empty((cin, cout, r, s), dtype=torch.bfloat16, device=wd.device, memory_format=torch.channels_last)
+        L.check(L.lib().dir_conv_prep_weights(L.ptr(wd), cout, r, s, cin, L.ptr(w16), L.ptr(w16_rot),
+                                              L.stream_ptr(wd.device)), "dir_conv_prep_weights")
         conv._dir_w16 = (key, w16, w16_rot)
     else:
         w16, w16_rot = cache[1], cache[2]

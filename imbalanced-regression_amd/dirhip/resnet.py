@@ -17,7 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .bn import bn_act
+from .bn import BatchCounters, bn_act
 from .conv import conv_bn_input, supported as _igemm_ok
 from .fds import FDS
 
@@ -115,8 +115,19 @@ class ResNet(nn.Module):
         x = self.avgpool(x)
         return x.view(x.size(0), -1)
 
+    def _batch_counters(self):
+        bc = getattr(self, "_dir_counters", None)
+        if bc is None or bc.flat is None or bc.flat.device != self.bn1.weight.device or \
+                self.bn1.num_batches_tracked.data_ptr() != bc.flat.data_ptr():
+            bc = BatchCounters().link(self)
+            object.__setattr__(self, "_dir_counters", bc)
+        return bc
+
     def forward(self, x, targets=None, epoch=None):
+        counters = self._batch_counters() if self.training else None
         encoding = self.features(x)
+        if counters is not None:
+            counters.flush()
         # the FDS / linear / loss tail is fp32 whatever precision the conv stack ran in
         with torch.autocast(device_type=encoding.device.type, enabled=False):
             if encoding.dtype != torch.float32:

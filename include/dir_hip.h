@@ -211,10 +211,12 @@ int dir_bn_fwd_train_partials(const void* x, const void* residual, void* y, int 
 int dir_bn_fwd_eval(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                     const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                     double eps, int relu, void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* `out` may be NULL for a ReLU layer WITHOUT residual: the mask is then recomputed from x with the forward's own
+ * coefficients (needs beta; bit-identical decision, one tensor read less per pass). */
 int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void* dres, int dtype,
-               int64_t M, int C, const float* gamma, const float* save_mean, const float* save_rstd,
-               float* dgamma, float* dbeta, int relu, void* workspace, size_t workspace_bytes,
-               dir_stream_t stream);
+               int64_t M, int C, const float* gamma, const float* beta, const float* save_mean,
+               const float* save_rstd, float* dgamma, float* dbeta, int relu, void* workspace,
+               size_t workspace_bytes, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  convolution as MFMA implicit GEMM, NHWC bf16, fp32 accumulation.  Replaces nn.Conv2d (bias=False) of
@@ -228,6 +230,10 @@ int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void*
  * rotated, in/out-transposed weights.
  */
 size_t dir_conv_stats_rows(int N, int Ho, int Wo);
+/* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
+ * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
+int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
+                          dir_stream_t stream);
 int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 
