@@ -18,6 +18,7 @@
 //   epilogue: bf16 rounding, optional per-channel (sum, sum of squares) partials of the rounded outputs for the
 //   following BatchNorm (no separate statistics pass over Y), LDS transpose staging, 16-B coalesced row stores.
 // Workgroup ids are remapped so that the N-tiles of one M-tile run on the same XCD (A tile re-reads hit that L2).
+#include <cstdlib>
 #include "dir_common.h"
 
 namespace {
@@ -35,6 +36,7 @@ struct ConvP {
     const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int M, KT, cpk, ntn, nblocks;
+    int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
 };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
@@ -56,7 +58,7 @@ conv_igemm_kernel(ConvP p) {
     constexpr int NI = 2;                                 //                      ... along N
     constexpr int WM = MI * 32;
     unsigned char* As = smem;
-    unsigned char* Bs = smem + 2 * A_BYTES;
+    unsigned char* Bs = smem + p.nbuf * A_BYTES;
 
     // ---- workgroup -> (m tile, n tile), XCD-aware and bijective
     int lin;
@@ -141,8 +143,9 @@ conv_igemm_kernel(ConvP p) {
     CV_STORE_TILE(0);
     __syncthreads();
     const int frow = lane & 31, fhalf = lane >> 5;
+    const bool dbuf = p.nbuf == 2;
     for (int kt = 0; kt < p.KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = dbuf ? (kt & 1) : 0;
         const bool more = kt + 1 < p.KT;
         if (more) CV_LOAD_TILE();                              // global loads in flight during the MFMAs
 #pragma unroll
@@ -165,7 +168,8 @@ conv_igemm_kernel(ConvP p) {
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (more) CV_STORE_TILE(buf ^ 1);
+        if (!dbuf) __syncthreads();                          // single stage: everyone is done reading before the overwrite
+        if (more) CV_STORE_TILE(dbuf ? (buf ^ 1) : 0);
         __syncthreads();
     }
 #undef CV_LOAD_TILE
@@ -173,23 +177,31 @@ conv_igemm_kernel(ConvP p) {
 #undef CV_ST
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
-    uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);          // [128][BN] bf16 staging (<= 32 KB, buffers are free now)
-    float* Ss = reinterpret_cast<float*>(smem + CV_BM * BN * 2);   // [4 waves][2][64] column partials
+    // Neighbouring lanes hold neighbouring columns, so lane pairs swap one value per register pair through DPP
+    // (quad_perm [1,0,3,2]) and every lane stores packed bf16x2 dwords: even lanes the even-numbered rows of the pair,
+    // odd lanes the odd ones. Staging rows are padded by 64 B so the two rows of a pair land on disjoint banks.
+    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row
+    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB, the K-loop buffers are free now)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
     float csum[NI], csq[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
+    const bool odd = lane & 1;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t h = cv_f2bf(acc[mi][ni][e]);
-                const int row = wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-                const int col = wn * 64 + ni * 32 + frow;
-                Cs[row * BN + col] = (uint16_t)h;
-                const float v = __uint_as_float(h << 16);        // statistics of what is actually stored
-                csum[ni] += v; csq[ni] += v * v;
+            for (int e = 0; e < 16; e += 2) {
+                const uint32_t h0 = cv_f2bf(acc[mi][ni][e]), h1 = cv_f2bf(acc[mi][ni][e + 1]);
+                const float f0 = __uint_as_float(h0 << 16), f1 = __uint_as_float(h1 << 16);   // statistics of what is stored
+                csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
+                const uint32_t send = odd ? h0 : h1;             // what the partner lane needs
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
+                const uint32_t packed = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
+                const int row = wm * WM + mi * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * fhalf;
+                const int col = wn * 64 + ni * 32 + (frow & ~1);
+                *reinterpret_cast<uint32_t*>(Cs + row * CS_STRIDE + col * 2) = packed;
             }
     if (p.stats) {
 #pragma unroll
@@ -213,7 +225,7 @@ conv_igemm_kernel(ConvP p) {
         const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
         if (m0 + row < p.M)
             *reinterpret_cast<uint4*>(p.y + (size_t)(m0 + row) * p.Cout + n0 + ch * 8) =
-                *reinterpret_cast<const uint4*>(Cs + row * BN + ch * 8);
+                *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
     }
 }
 
@@ -244,14 +256,23 @@ extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats,
     p.ntn = wide ? Cout / 128 : Cout / 64;
     p.nblocks = mtiles * p.ntn;
     hipStream_t s = dir_s(stream);
+    // LDS stages: 2 (64 KB, 2 workgroups per CU) for long K loops, 1 (43 KB, 3 per CU) when the loop is short and the
+    // layer is bound by memory latency rather than by MFMA issue. DIR_CONV_NBUF=1|2 overrides (experiments).
+    static const int force_nbuf = []() { const char* e = getenv("DIR_CONV_NBUF"); return e ? atoi(e) : 0; }();
+    static const int nbuf_kt = []() { const char* e = getenv("DIR_CONV_NBUF_KT"); return e ? atoi(e) : 18; }();
+    p.nbuf = force_nbuf ? force_nbuf : (p.KT <= nbuf_kt ? 1 : 2);
     if (wide) {
-        constexpr int lds = 2 * (CV_BM * CV_ROWB + 128 * CV_ROWB);
+        const int stage = CV_BM * (128 * 2 + 64) + 2048;            // epilogue staging + column partials
+        const int loop = p.nbuf * (CV_BM * CV_ROWB + 128 * CV_ROWB);
+        const int lds = loop > stage ? loop : stage;
         static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
         (void)once;
         hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
     } else {
-        constexpr int lds = 2 * (CV_BM * CV_ROWB + 64 * CV_ROWB);
+        const int stage = CV_BM * (64 * 2 + 64) + 2048;
+        const int loop = p.nbuf * (CV_BM * CV_ROWB + 64 * CV_ROWB);
+        const int lds = loop > stage ? loop : stage;
         hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
     }
     DIR_LAUNCH_CHECK();
