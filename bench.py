@@ -178,6 +178,74 @@ def kernel_rooflines(device):
     return out
 
 
+# ResNet-50 convolutions that run on the hand-written MFMA kernel (every layer but the 7x7 stem):
+# (Cin, Cout, k, stride, Hin, count) — SURVEY.md Appendix B
+RESNET50_CONVS = [(64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2), (256, 128, 1, 1, 56, 1),
+                  (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1), (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3),
+                  (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1), (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5),
+                  (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
+                  (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2)]
+
+
+def conv_roofline(device, batch):
+    """Dominant kernel of the step = conv_igemm_kernel (forward + stride-1 data-gradient launches, ~1/3 of the GPU
+    time). Algorithmic FLOPs per launch = 2*M*Cout*Cin*R*S (implicit GEMM, SURVEY.md §8d: 8.174 GFLOP/image forward);
+    duration = HIP events on the launch stream, 5 launches per layer shape, every layer shape of the network in its
+    forward and (stride-1 layers) data-gradient configuration."""
+    from dirhip.conv import conv2d_igemm
+    tot_flop = tot_ms = 0.0
+    launches = 0
+    per_kind = {}
+    for cin, cout, k, st, h, cnt in RESNET50_CONVS:
+        pad = k // 2
+        ho = (h + 2 * pad - k) // st + 1
+        cfgs = [("fwd", cin, cout, h, st)]
+        if st == 1:
+            cfgs.append(("dgrad", cout, cin, ho, 1))          # same kernel on dY with rotated weights
+        for kind, ci, co, hh, s_ in cfgs:
+            x = torch.randn(batch, ci, hh, hh, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            w = (torch.randn(co, ci, k, k, device=device) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            ms = event_time_ms(lambda: conv2d_igemm(x, w, s_, pad, want_stats=(kind == "fwd")), 5, warm=2)
+            hout = (hh + 2 * pad - k) // s_ + 1
+            flop = 2.0 * batch * hout * hout * co * ci * k * k
+            tot_flop += flop * cnt
+            tot_ms += ms * cnt
+            launches += cnt
+            a = per_kind.setdefault(kind, [0.0, 0.0])
+            a[0] += flop * cnt
+            a[1] += ms * cnt
+            del x, w
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<128|64> (hand-written MFMA implicit GEMM; all 52 conv layers fwd + 46 stride-1 dgrad)",
+            "achieved": tot_flop / tot_ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": tot_flop / tot_ms / 1e9 / PEAK_BF16_TFLOPS, "traffic": None,
+            "launches_per_step": launches, "avg_launch_us": tot_ms / launches * 1e3,
+            "algorithmic_flop_per_step": tot_flop, "ms_per_step_in_this_kernel": tot_ms,
+            "fwd_tflops": per_kind["fwd"][0] / per_kind["fwd"][1] / 1e9, "dgrad_tflops": per_kind["dgrad"][0] / per_kind["dgrad"][1] / 1e9}
+
+
+def bn_roofline(device, batch):
+    """Fused BatchNorm(+residual)(+ReLU) forward apply / backward on the widest layer-1 tensor (HBM bound)."""
+    import torch.nn as nn
+    from dirhip.bn import bn_act
+    out = []
+    c, hw = 256, 56
+    x = torch.randn(batch, c, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = torch.randn_like(x).requires_grad_(True)
+    dy = torch.randn_like(x)
+    bn = nn.BatchNorm2d(c).to(device)
+    nbytes = x.numel() * 2
+    tf = event_time_ms(lambda: bn_act(x, bn, True, r), 10)
+
+    def fb():
+        bn_act(x, bn, True, r).backward(dy)
+    tb = event_time_ms(fb, 10) - tf
+    for name, ms, passes in (("dir_bn_fwd_train (stats + finalize + apply, residual+ReLU)", tf, 4), ("dir_bn_bwd (reduce + finalize + apply, residual+ReLU)", tb, 8)):
+        out.append({"kernel": name, "bound": "hbm", "shape": f"[{batch},{c},{hw},{hw}] bf16 NHWC", "ms": ms,
+                    "algorithmic_bytes": passes * nbytes, "achieved": passes * nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": passes * nbytes / ms / 1e6 / PEAK_HBM_GBS})
+    return out
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle port (torch-CPU restatement of the reference loop) on the host cores: ResNet-50 + FDS + LDS
     weights + l1 + Adam, B=8 (BASELINE configs[0] batch), epoch tail included every 4 steps."""
@@ -269,16 +337,20 @@ def main():
                    "epoch_len_steps": args.epoch_len, "epoch_tails_in_timed_region": n_tails, "parallelism": f"dp{world}",
                    "final_loss": loss_val},
         "train_only_images_per_sec": images / dt_train,
-        "roofline": {"bound": "mfma", "kernel": "whole train loop per GPU: ResNet-50 conv stack fwd+bwd (+ fwd-only epoch tail)",
-                     "achieved": flops / dt / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops / dt / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
-                     "train_only_frac": args.steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / PEAK_BF16_TFLOPS},
+        # whole-loop MFMA fraction (24.287 GFLOP per trained image + 8.174 per tail-forward image over the wall clock)
+        "roofline_loop": {"bound": "mfma", "kernel": "whole train loop per GPU: ResNet-50 fwd+bwd (+ fwd-only epoch tail)",
+                          "achieved": flops / dt / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                          "frac": flops / dt / 1e12 / PEAK_BF16_TFLOPS,
+                          "train_only_frac": args.steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / PEAK_BF16_TFLOPS},
     }
+    result["roofline"] = dict(result["roofline_loop"], traffic=None)      # replaced below by the dominant kernel's when measured
     if rank == 0 and world == 1:
         del engine, optimizer, batches, store
         torch.cuda.empty_cache()
         if not args.no_kernel_rooflines:
-            result["kernel_rooflines"] = kernel_rooflines(device)
+            result["roofline"] = conv_roofline(device, args.batch)
+            log("conv roofline done")
+            result["kernel_rooflines"] = kernel_rooflines(device) + bn_roofline(device, args.batch)
             log("kernel rooflines done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
