@@ -54,7 +54,11 @@ class _Bucket:
         self.views = []
         off = 0
         for p in params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            # same memory layout as the parameter (e.g. channels_last conv weights): fused / multi-tensor optimizer
+            # kernels walk parameter and gradient storage with one linear index, so the layouts must agree
+            seg = self.flat[off:off + p.numel()]
+            dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) if p.dim() == 4 else p.is_contiguous()
+            self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
             off += p.numel()
         self.pending = len(params)
         self.work = None

@@ -10,6 +10,10 @@ import torch.nn as nn
 
 def _net():
     torch.manual_seed(3)
+    return _net_raw().to(memory_format=torch.channels_last)      # conv weights NHWC-strided like the real model
+
+
+def _net_raw():
     return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(),
                          nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 1))
 
@@ -36,6 +40,9 @@ def _worker(rank, world, port, tmp):
         loss.backward()
         opt.step()
     assert len(eng._buckets) >= 2
+    for b in eng._buckets:                                  # gradient views share the parameters' memory layout
+        for prm, v in zip(b.params, b.views):
+            assert v.stride() == prm.stride() and prm.grad.data_ptr() == v.data_ptr()
     assert all(k.startswith("module.") for k in eng.state_dict())
     torch.save({k: v.clone() for k, v in eng.module.state_dict().items()}, os.path.join(tmp, f"w{rank}.pt"))
     dist.destroy_process_group()
