@@ -126,32 +126,35 @@ bn_stats_partial_kernel(const T* __restrict__ x, int64_t M, int C, BnGeom g, flo
 }
 
 
-// Sum partial[b][which][c] over b for 8 channels per workgroup: 256 threads = 8 channels x 32 slices of the
-// row-block axis, float64, LDS tree. Returns the two sums for channel (blockIdx.x*8 + (t & 7)) in lanes t < 8.
-#define FIN_CH 8
-#define FIN_SL (DIR_TPB / FIN_CH)
+// Sum partial[b][which][c] over b for FC channels per workgroup: 256 threads = FC channels x (256/FC) slices of the
+// row-block axis, float64, fixed-order LDS combine. FC = 8 for short partial lists; FC = 2 (128 slices) when the
+// conv epilogue produced thousands of rows (one per 128-row tile) — the loop is a chain of L2 round trips, so its
+// length, not the bytes, is what costs. Returns the two sums for channel blockIdx.x*FC + t in threads t < FC.
+template <int FC>
 __device__ __forceinline__ bool column_sums(const float* __restrict__ partial, int rblocks, int C, double& s0, double& s1) {
+    constexpr int SL = DIR_TPB / FC;
     __shared__ double sh[2][DIR_TPB];
-    const int t = threadIdx.x, ch = t & (FIN_CH - 1), sl = t / FIN_CH;
-    const int c = blockIdx.x * FIN_CH + ch;
+    const int t = threadIdx.x, ch = t % FC, sl = t / FC;
+    const int c = blockIdx.x * FC + ch;
     double a = 0.0, b = 0.0;
     if (c < C) {
-#pragma unroll 4
-        for (int r = sl; r < rblocks; r += FIN_SL) {
+#pragma unroll 8
+        for (int r = sl; r < rblocks; r += SL) {
             a += (double)partial[((size_t)r * 2 + 0) * C + c];
             b += (double)partial[((size_t)r * 2 + 1) * C + c];
         }
     }
     sh[0][t] = a; sh[1][t] = b;
     __syncthreads();
-    if (t >= FIN_CH || c >= C) return false;
+    if (t >= FC || c >= C) return false;
     a = 0.0; b = 0.0;
-    for (int k = 0; k < FIN_SL; ++k) { a += sh[0][k * FIN_CH + t]; b += sh[1][k * FIN_CH + t]; }
+    for (int k = 0; k < SL; ++k) { a += sh[0][k * FC + t]; b += sh[1][k * FC + t]; }
     s0 = a; s1 = b;
     return true;
 }
 
 // coef layout in the workspace: [0][C] = a (scale), [1][C] = b (shift)
+template <int FC>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_finalize_train_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -159,8 +162,8 @@ bn_finalize_train_kernel(const float* __restrict__ partial, int rblocks, int64_t
                          double momentum, double eps, float* __restrict__ save_mean, float* __restrict__ save_rstd,
                          float* __restrict__ coef) {
     double s, q;
-    if (!column_sums(partial, rblocks, C, s, q)) return;
-    const int c = blockIdx.x * FIN_CH + threadIdx.x;
+    if (!column_sums<FC>(partial, rblocks, C, s, q)) return;
+    const int c = blockIdx.x * FC + threadIdx.x;
     const double n = (double)M;
     const double mean = s / n;
     double var = q / n - mean * mean;                     // biased (normalisation)
@@ -301,14 +304,15 @@ bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const
 
 // dbeta = sum g;  dgamma = rstd * (sum g*x - mean * sum g);  dx = a*g + p*x + q with
 // a = gamma*rstd, p = -a*rstd*dgamma/M, q = -a*dbeta/M - p*mean.   coef: [0]=a [1]=p [2]=q
+template <int FC>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_bwd_finalize_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
                        const float* __restrict__ save_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                        float* __restrict__ coef) {
     double sg, sgx;
-    if (!column_sums(partial, rblocks, C, sg, sgx)) return;
-    const int c = blockIdx.x * FIN_CH + threadIdx.x;
+    if (!column_sums<FC>(partial, rblocks, C, sg, sgx)) return;
+    const int c = blockIdx.x * FC + threadIdx.x;
     const double mean = (double)save_mean[c], rstd = (double)save_rstd[c], n = (double)M;
     const double dg = rstd * (sgx - mean * sg);
     dbeta[c] = (float)sg;
@@ -414,8 +418,12 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
             hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
             DIR_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(dir_cdiv(C, FIN_CH)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
-                           running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+        if (prow > 512)
+            hipLaunchKernelGGL(bn_finalize_train_kernel<2>, dim3(dir_cdiv(C, 2)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
+                               running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+        else
+            hipLaunchKernelGGL(bn_finalize_train_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
+                               running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
     } else {
         hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
     }
@@ -447,7 +455,7 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     else if (mask == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 2>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 0>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dir_cdiv(C, FIN_CH)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(dir_cdiv(C, 8)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
                        save_mean, save_rstd, dgamma, dbeta, w.coef);
     DIR_LAUNCH_CHECK();
     if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);

@@ -1,0 +1,120 @@
+// 3x3 / stride 2 / pad 1 max pooling for NHWC bf16 activations (the stem pool of imdb-wiki-dir/resnet.py:82,131),
+// forward with an argmax byte per element and a gather-style (atomic-free) backward. HBM-bound streaming kernels:
+// a thread owns 8 consecutive channels (16 B) of one pixel.
+#include "dir_common.h"
+
+namespace {
+
+__device__ __forceinline__ float pl_bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+
+__global__ void __launch_bounds__(DIR_TPB)
+maxpool_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, uint8_t* __restrict__ idx,
+                   int N, int H, int W, int C, int Ho, int Wo) {
+    const int cg = C / 8;
+    const long long total = (long long)N * Ho * Wo * cg;
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < total; i += (long long)gridDim.x * DIR_TPB) {
+        const int g = (int)(i % cg); long long p = i / cg;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+        float best[8]; uint32_t bi[8], raw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; raw[j] = 0xff80u; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + hi) * W + wi) * C + g * 8);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t lo = w4[q] & 0xffffu, hi16 = w4[q] >> 16;
+                    const float f0 = pl_bf2f(lo), f1 = pl_bf2f(hi16);
+                    if (f0 > best[2 * q] || f0 != f0) { best[2 * q] = f0; bi[2 * q] = r * 3 + s; raw[2 * q] = lo; }        // first max wins
+                    if (f1 > best[2 * q + 1] || f1 != f1) { best[2 * q + 1] = f1; bi[2 * q + 1] = r * 3 + s; raw[2 * q + 1] = hi16; }
+                }
+            }
+        }
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+        *reinterpret_cast<uint4*>(y + o) = make_uint4(raw[0] | (raw[1] << 16), raw[2] | (raw[3] << 16), raw[4] | (raw[5] << 16), raw[6] | (raw[7] << 16));
+        *reinterpret_cast<uint2*>(idx + o) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                        bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+    }
+}
+
+// dx[n,h,w,c] = sum over the (<= 2x2) windows containing (h,w) whose argmax is (h,w) of dy[window]
+__global__ void __launch_bounds__(DIR_TPB)
+maxpool_bwd_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx,
+                   int N, int H, int W, int C, int Ho, int Wo) {
+    const int cg = C / 8;
+    const long long total = (long long)N * H * W * cg;
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < total; i += (long long)gridDim.x * DIR_TPB) {
+        const int g = (int)(i % cg); long long p = i / cg;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); const int n = (int)(p / H);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        // windows with 2*ho - 1 <= h <= 2*ho + 1  ->  ho in {(h-1+1)/2 ...}: ho = (h + 1) / 2 and, if h odd, also (h - 1) / 2 ... enumerate both candidates
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ho = (h + 1) / 2 - a;                     // r = h - (2*ho - 1)
+            const int r = h - (2 * ho - 1);
+            if (ho < 0 || ho >= Ho || r < 0 || r > 2) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int wo = (w + 1) / 2 - b;
+                const int s = w - (2 * wo - 1);
+                if (wo < 0 || wo >= Wo || s < 0 || s > 2) continue;
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+                const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+                const uint4 gv = *reinterpret_cast<const uint4*>(dy + o);
+                const uint32_t me = (uint32_t)(r * 3 + s);
+                const uint32_t g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t k = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t hbits = (j & 1) ? (g4[j >> 1] >> 16) : (g4[j >> 1] & 0xffffu);
+                    if (k == me) acc[j] += pl_bf2f(hbits);
+                }
+            }
+        }
+        uint32_t o16[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t u = __float_as_uint(acc[j]);
+            o16[j] = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        *reinterpret_cast<uint4*>(dx + (((size_t)n * H + h) * W + w) * C + g * 8) =
+            make_uint4(o16[0] | (o16[1] << 16), o16[2] | (o16[3] << 16), o16[4] | (o16[5] << 16), o16[6] | (o16[7] << 16));
+    }
+}
+
+}  // namespace
+
+extern "C" int dir_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const uint16_t*>(x),
+                       static_cast<uint16_t*>(y), static_cast<uint8_t*>(argmax), N, H, W, C, Ho, Wo);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !dx || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * H * W * (C / 8);
+    int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const uint16_t*>(dy),
+                       static_cast<const uint8_t*>(argmax), static_cast<uint16_t*>(dx), N, H, W, C, Ho, Wo);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

@@ -248,6 +248,12 @@ int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W
                    int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
                    dir_stream_t stream);
 
+/* 3x3 / stride 2 / pad 1 max pooling, NHWC bf16 (resnet.py:82,131 nn.MaxPool2d) with one argmax byte (0..8 = r*3+s,
+ * first maximum in scan order like torch) per output element; backward is a gather over the <= 2x2 windows that
+ * contain an input pixel (no atomics).  x [N,H,W,C], y/argmax [N,Ho,Wo,C], Ho = (H-1)/2+1;  C % 8 == 0. */
+int dir_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);
+int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,21 @@ def test_resnet50_forward_fp32_vs_reference_golden(golden):
     assert isinstance(out, tuple) and out[1].shape == (2, 2048)
     assert_close(out[0].cpu().numpy(), g["ref_pred_train"], rtol=2e-3, atol_scale=2e-3, msg="train pred")
     assert_close(out[1].cpu().numpy(), g["ref_enc_train"], rtol=2e-3, atol_scale=2e-3, msg="train encoding")
+
+
+def test_maxpool3x3s2_matches_torch():
+    from dirhip.pool import maxpool3x3s2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for shape in ((4, 64, 112, 112), (3, 64, 9, 7), (2, 8, 5, 6)):
+        x = torch.relu(torch.randn(shape, device="cuda", generator=g)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        pool = nn.MaxPool2d(3, 2, 1)
+        y = maxpool3x3s2(x, pool)
+        dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        xr = x.detach().float().requires_grad_(True)
+        yr = pool(xr)
+        yr.backward(dy.float())
+        assert torch.equal(y.float(), yr)                                  # max of bf16 values is exact
+        # ties (many exact zeros after ReLU) must route the gradient like torch: first maximum in scan order
+        assert_close(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-2, atol_scale=1e-2, msg=str(shape))
