@@ -34,6 +34,7 @@ __device__ __forceinline__ uint4 cv_gload(const uint16_t* base, ptrdiff_t elem_o
 
 struct ConvP {
     const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
+    const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int M, KT, cpk, ntn, nblocks;
     int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
@@ -223,9 +224,23 @@ conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < (CV_BM * CPR) / DIR_TPB; ++i) {
         const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
-        if (m0 + row < p.M)
-            *reinterpret_cast<uint4*>(p.y + (size_t)(m0 + row) * p.Cout + n0 + ch * 8) =
-                *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
+        if (m0 + row < p.M) {
+            uint4 c = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
+            const size_t go = (size_t)(m0 + row) * p.Cout + n0 + ch * 8;
+            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
+                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
+                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = __uint_as_float(cw[q] << 16) + __uint_as_float(aw[q] << 16);
+                    const float hi = __uint_as_float(cw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+                    cw[q] = cv_f2bf(lo) | (cv_f2bf(hi) << 16);
+                }
+                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            }
+            *reinterpret_cast<uint4*>(p.y + go) = c;
+        }
     }
 }
 
@@ -236,9 +251,18 @@ extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
     return (size_t)((M + CV_BM - 1) / CV_BM);
 }
 
+extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
+                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
+
 extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                             int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
+    return dir_conv_fwd_add(x, w, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+}
+
+extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
+                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
+    DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
@@ -249,6 +273,7 @@ extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats,
     ConvP p;
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
     p.stats = stats;
+    p.addend = static_cast<const uint16_t*>(addend);
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
     const int mtiles = (int)((M + CV_BM - 1) / CV_BM);

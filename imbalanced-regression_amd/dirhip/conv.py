@@ -13,7 +13,7 @@ def supported(cin, cout):
     return cin % 64 == 0 and cout % 64 == 0
 
 
-def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False):
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None):
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -31,8 +31,12 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False):
     if want_stats:
         rows = L.lib().dir_conv_stats_rows(n, ho, wo)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
-    L.check(L.lib().dir_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), n, h, wd, cin, cout, r, s, stride, padding,
-                                 L.stream_ptr(x.device)), "dir_conv_fwd")
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == torch.bfloat16 and not want_stats
+        if not addend.is_contiguous(memory_format=torch.channels_last):
+            addend = addend.contiguous(memory_format=torch.channels_last)
+    L.check(L.lib().dir_conv_fwd_add(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(y), L.ptr(stats), n, h, wd, cin, cout, r, s,
+                                     stride, padding, L.stream_ptr(x.device)), "dir_conv_fwd")
     return (y, stats) if want_stats else y
 
 
@@ -62,19 +66,26 @@ class _ConvFn(torch.autograd.Function):
     kernel ``dir_conv_wgrad``. Only the data gradient of the six stride-2 layers still uses the library kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats):
+    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input):
         ctx.stride, ctx.padding = stride, padding
+        ctx.alias_input = alias_input
         if want_stats:
             y, stats = conv2d_igemm(x, w16, stride, padding, want_stats=True)
             ctx.mark_non_differentiable(stats)
         else:
             y, stats = conv2d_igemm(x, w16, stride, padding), None
         ctx.save_for_backward(x, w16, w16_rot)
-        return y, stats
+        if alias_input:
+            # second output = the input itself (for the identity shortcut): its gradient arrives in backward() together
+            # with dy, so the accumulation dX = dgrad(dy) + d_shortcut happens inside the dgrad kernel's store loop
+            return y, stats, x
+        return y, stats, None
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, dalias=None):
         x, w16, w16_rot = ctx.saved_tensors
+        if dalias is not None and dalias.dtype != torch.bfloat16:
+            dalias = dalias.to(torch.bfloat16)
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -83,14 +94,17 @@ class _ConvFn(torch.autograd.Function):
         if need_dx and w16_rot is not None:
             # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
             # in/out-transposed weights and padding R-1-pad
-            dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding)
+            dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias)
+            dalias = None
             need_dx = False
         dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
         if need_dx:                                                              # strided data gradient: library kernel for now
             dx = torch.ops.aten.convolution_backward(
                 dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
                 [True, False, False])[0]
-        return dx, dw, None, None, None, None, None
+        if dalias is not None:                                                   # strided layer: eager accumulation
+            dx = dalias if dx is None else dx + dalias
+        return dx, dw, None, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -107,7 +121,7 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_hook(invalidate_weight_cache)
 
 
-def conv_bn_input(x, conv, want_stats):
+def conv_bn_input(x, conv, want_stats, alias_input=False):
     """Apply ``conv`` (an ``nn.Conv2d`` with bias=False, Cin/Cout multiples of 64) to a bf16 channels_last tensor with
     the MFMA kernel. Returns ``(y, partial_stats or None)``. The bf16 copy of the fp32 master weight is cached until
     the next optimizer step / in-place edit (one cast per step instead of one per use: train forward, epoch-tail
@@ -132,4 +146,8 @@ def conv_bn_input(x, conv, want_stats):
         w16, w16_rot = cache[1], cache[2]
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
-    return _ConvFn.apply(x, w, w16, w16_rot if torch.is_grad_enabled() else None, conv.stride[0], conv.padding[0], want_stats)
+    y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if torch.is_grad_enabled() else None, conv.stride[0],
+                                    conv.padding[0], want_stats, alias_input and torch.is_grad_enabled() and x.requires_grad)
+    if alias_input:
+        return y, stats, (alias if alias is not None else x)
+    return y, stats

@@ -53,8 +53,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        y = _conv_bn(x, self.conv1, self.bn1, relu=True)
+        if self.downsample is None and x.dtype == torch.bfloat16 and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels):
+            # identity shortcut: conv1's node also hands back the block input, so the two gradients that meet at the
+            # block input are summed inside conv1's data-gradient kernel instead of by an eager add
+            y, partial, shortcut = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True)
+            y = bn_act(y, self.bn1, relu=True, partial=partial)
+        else:
+            shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
+            y = _conv_bn(x, self.conv1, self.bn1, relu=True)
         y = _conv_bn(y, self.conv2, self.bn2, relu=True)
         return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut)    # relu(bn3(conv3(.)) + shortcut)
 

@@ -236,6 +236,11 @@ int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void*
                           dir_stream_t stream);
 int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
+/* y = bf16(bf16(conv(x, w)) + addend): the gradient accumulation autograd would run as a separate add kernel at a
+ * fan-out (block input feeding conv1 and the identity shortcut), fused into the data-gradient convolution's store
+ * loop.  addend [N, Ho, Wo, Cout] bf16; stats must be NULL. */
+int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
+                     int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the

@@ -120,3 +120,39 @@ def test_conv_wgrad_matches_fp32_reference(case):
     assert_close(dw.cpu().numpy(), wref.grad.cpu().numpy(), rtol=2e-4, atol_scale=2e-4, msg=str(case))
     # deterministic split-K: bit-identical on a second run
     assert torch.equal(dw, conv2d_wgrad(dy, x, k, stride, pad))
+
+
+def test_bottleneck_fused_shortcut_gradient_matches_unfused():
+    """Identity-shortcut bottleneck: the gradient accumulation at the block input (dgrad(conv1) + d shortcut) fused into
+    conv1's data-gradient kernel must give the same input/parameter gradients as autograd's eager add."""
+    from dirhip import resnet as R
+    torch.manual_seed(0)
+    blk = R.Bottleneck(256, 64).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0 = torch.randn(8, 256, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, 256, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        for p in blk.parameters():
+            p.grad = None
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        xin = x * 1.0                                        # non-leaf input like inside the network
+        if fused:
+            out = blk(xin)
+        else:
+            sc = xin
+            y = R._conv_bn(xin, blk.conv1, blk.bn1, relu=True)
+            y = R._conv_bn(y, blk.conv2, blk.bn2, relu=True)
+            out = R._conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=sc)
+        out.backward(dy)
+        return out.detach().float(), x.grad.float(), [p.grad.clone() for p in blk.parameters()]
+
+    o1, gx1, gp1 = run(True)
+    o2, gx2, gp2 = run(False)
+    assert torch.equal(o1, o2)
+    assert_close(gx1.cpu().numpy(), gx2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
+    for a, b in zip(gp1, gp2):
+        assert torch.equal(a, b)
