@@ -215,9 +215,18 @@ def conv_roofline(device, batch):
             a[0] += flop * cnt
             a[1] += ms * cnt
             del x, w
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; they come from the separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 98 launches (tools/pmc_conv_pass.py ->
+    # tools/pmc_conv_parse.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/.
+    traffic = traffic_alg = None
+    tpath = os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json")
+    if os.path.isfile(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("batch") == batch and tj.get("launches_per_step") == launches:
+            traffic, traffic_alg = tj["traffic_bytes_per_launch"], tj["algorithmic_bytes_per_step"] / launches
     return {"bound": "mfma", "kernel": "conv_igemm_kernel<128|64> (hand-written MFMA implicit GEMM; all 52 conv layers fwd + 46 stride-1 dgrad)",
             "achieved": tot_flop / tot_ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": tot_flop / tot_ms / 1e9 / PEAK_BF16_TFLOPS, "traffic": None,
+            "frac": tot_flop / tot_ms / 1e9 / PEAK_BF16_TFLOPS, "traffic": traffic, "algorithmic_bytes_per_launch": traffic_alg,
             "launches_per_step": launches, "avg_launch_us": tot_ms / launches * 1e3,
             "algorithmic_flop_per_step": tot_flop, "ms_per_step_in_this_kernel": tot_ms,
             "fwd_tflops": per_kind["fwd"][0] / per_kind["fwd"][1] / 1e9, "dgrad_tflops": per_kind["dgrad"][0] / per_kind["dgrad"][1] / 1e9}
