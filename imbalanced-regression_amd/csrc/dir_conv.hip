@@ -37,6 +37,8 @@ struct ConvP {
     const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int M, KT, cpk, ntn, nblocks;
+    int simple;               // 1x1, stride 1, pad 0: row m of the GEMM is row m of x (no index arithmetic at all)
+    float inv_wo, inv_ho;     // reciprocals for the (n, ho, wo) decode of the general case
     int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
 };
 
@@ -84,7 +86,12 @@ conv_igemm_kernel(ConvP p) {
         const int m = m0 + lrow + 32 * i;
         aoff[i] = 0; amask[i] = 0;
         if (m < p.M) {
-            const int wo = m % p.Wo, tmp = m / p.Wo, ho = tmp % p.Ho, n = tmp / p.Ho;
+            if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }
+            // (n, ho, wo) from m: float reciprocal + one correction step instead of integer divisions (exact for m < 2^24)
+            int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+            if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+            int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+            if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
             aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;
             for (int r = 0; r < p.R; ++r)
@@ -269,13 +276,15 @@ extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     const long long M = (long long)N * Ho * Wo;
-    DIR_RETURN_IF(M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);
     ConvP p;
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
     p.stats = stats;
     p.addend = static_cast<const uint16_t*>(addend);
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
+    p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    p.inv_wo = 1.0f / (float)Wo; p.inv_ho = 1.0f / (float)Ho;
     const int mtiles = (int)((M + CV_BM - 1) / CV_BM);
     const bool wide = (Cout % 128 == 0);
     p.ntn = wide ? Cout / 128 : Cout / 64;
