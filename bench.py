@@ -306,6 +306,7 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
+    args.epoch_len = max(1, min(args.epoch_len, args.steps))      # at least one epoch tail inside the timed region
     from dirhip.parallel import init_distributed
     rank, world, local_rank = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -321,7 +322,14 @@ def main():
     loss_fn = resolve_loss("l1")
 
     log("model + data built")
-    _, epoch = run_steps(engine, optimizer, batches, store, args.warmup, args.epoch_len, 2, loss_fn)
+    # set-up, not warm-up: the first step makes the library pick kernels for the few layers still on it (stem conv,
+    # stride-2 data gradients: ~17 s of solver search on a fresh box); one step + one tail forward, untimed
+    from dirhip.train_loop import epoch_tail, train_step
+    train_step(engine, optimizer, *batches[0], 2, loss_fn)
+    epoch_tail(engine, [(batches[0][0], batches[0][1])], 2, store)
+    torch.cuda.synchronize(device)
+    log("set-up step done")
+    _, epoch = run_steps(engine, optimizer, batches, store, args.warmup, args.epoch_len, 3, loss_fn)
     torch.cuda.synchronize(device)
     log("warmup done")
     dt, (loss, epoch) = timed(lambda: run_steps(engine, optimizer, batches, store, args.steps, args.epoch_len, epoch, loss_fn),

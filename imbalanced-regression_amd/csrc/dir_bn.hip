@@ -418,11 +418,9 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
             hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
             DIR_LAUNCH_CHECK();
         }
-        if (prow > 512)
-            hipLaunchKernelGGL(bn_finalize_train_kernel<2>, dim3(dir_cdiv(C, 2)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
-                               running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
-        else
-            hipLaunchKernelGGL(bn_finalize_train_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
+        // (a 2-channel x 128-slice variant for the conv epilogue's long partial lists measured slower — 16.6 vs 11.5 us:
+        //  its 8-byte loads touch 32 cache lines per wave instruction)
+        hipLaunchKernelGGL(bn_finalize_train_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
                                running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
     } else {
         hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
