@@ -604,3 +604,116 @@ extern "C" int dir_fds_smooth_fwd(void* x_inout, int dtype, const float* labels,
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
+
+// =============================================================================================
+// STS-B variant (sts-b-dir/fds.py, sts-b-dir/util.py:63-73): histogram-edge bins, guarded calibration,
+// empty-bucket fill
+// =============================================================================================
+// bin = bucket_num - 1 if label == last edge, else max((first i with edges[i] > label) - 1, bucket_start)
+// (fds.py:51-57 `_get_bucket_idx`); -1 (row skipped) where the reference would raise (label beyond the last edge, NaN).
+__global__ void __launch_bounds__(DIR_TPB)
+fds_bin_edges_kernel(const float* __restrict__ labels, int n, const float* __restrict__ edges, int nedges,
+                     int bucket_start, int bucket_num, int32_t* __restrict__ bins) {
+    extern __shared__ float sh_edges[];
+    for (int i = threadIdx.x; i < nedges; i += DIR_TPB) sh_edges[i] = edges[i];
+    __syncthreads();
+    for (int i = blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += gridDim.x * DIR_TPB) {
+        const float l = labels[i];
+        int b = -1;
+        if (l == sh_edges[nedges - 1]) b = bucket_num - 1;
+        else {
+            int first = -1;
+            for (int k = 0; k < nedges; ++k) if (sh_edges[k] > l) { first = k; break; }
+            if (first >= 0) { b = first - 1; if (b < bucket_start) b = bucket_start; }
+        }
+        bins[i] = (b < 0) ? -1 : b - bucket_start;
+    }
+}
+
+extern "C" int dir_fds_bin_edges(const float* labels, int n, const float* edges, int nedges, int bucket_start,
+                                 int bucket_num, int32_t* bins, dir_stream_t stream) {
+    DIR_RETURN_IF(!labels || !edges || !bins || n < 0 || nedges < 2 || nedges > 4096, DIR_EINVAL);
+    DIR_RETURN_IF(check_buckets(bucket_start, bucket_num), DIR_EINVAL);
+    if (n == 0) return DIR_OK;
+    int grid = dir_cdiv(n, DIR_TPB); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(fds_bin_edges_kernel, dim3(grid), dim3(DIR_TPB), sizeof(float) * nedges, dir_s(stream),
+                       labels, n, edges, nedges, bucket_start, bucket_num, bins);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// "make up for zero training samples buckets" (sts-b-dir/fds.py:112-125): buckets without samples in this call take
+// their neighbours' values, in increasing bucket order (so a run of empty buckets propagates from the left).
+__global__ void __launch_bounds__(DIR_TPB)
+fds_fill_empty_kernel(const double* __restrict__ count, int nb, int C, float* __restrict__ rm, float* __restrict__ rv) {
+    const int c = blockIdx.x * DIR_TPB + threadIdx.x;
+    if (c >= C) return;
+    for (int b = 0; b < nb; ++b) {
+        if (count[b] > 0.0) continue;
+        if (b == 0) { if (nb > 1) { rm[c] = rm[C + c]; rv[c] = rv[C + c]; } }
+        else if (b == nb - 1) { rm[(size_t)b * C + c] = rm[(size_t)(b - 1) * C + c]; rv[(size_t)b * C + c] = rv[(size_t)(b - 1) * C + c]; }
+        else {
+            rm[(size_t)b * C + c] = (rm[(size_t)(b - 1) * C + c] + rm[(size_t)(b + 1) * C + c]) / 2.0f;
+            rv[(size_t)b * C + c] = (rv[(size_t)(b - 1) * C + c] + rv[(size_t)(b + 1) * C + c]) / 2.0f;
+        }
+    }
+}
+
+extern "C" int dir_fds_fill_empty_buckets(const double* count, int nb, int C, float* running_mean, float* running_var,
+                                          dir_stream_t stream) {
+    DIR_RETURN_IF(!count || !running_mean || !running_var || nb <= 0 || C <= 0, DIR_EINVAL);
+    hipLaunchKernelGGL(fds_fill_empty_kernel, dim3(dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream), count, nb, C,
+                       running_mean, running_var);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// Multiplier table with the STS-B / NYUD2 guards (sts-b-dir/util.py:63-73, nyud2-dir/util.py:151-162).
+//   guard_mode 0: age variant — a column is left untouched when v1 == 0.
+//   guard_mode 1: the reference AS IT EXECUTES on torch >= 1.2 — `((v1 > 0.) + (v2 >= 0.)) == 2` adds two bool
+//                 tensors (logical or) and compares with 2, which is never true, so as soon as ANY column of the row
+//                 has v1 <= 0 or v2 < 0 the WHOLE row is returned unchanged.
+//   guard_mode 2: the evident intent (and the behaviour on the torch 0.4.1 the STS-B project pins): only the columns
+//                 with v1 <= 0 or v2 < 0 are left untouched.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_prepare_scale_ex_kernel(const float* __restrict__ v1, const float* __restrict__ v2, int C, float clip_min,
+                            float clip_max, int guard_mode, float* __restrict__ scale) {
+    __shared__ double wsum[DIR_TPB / DIR_WAVE];
+    const int b = blockIdx.x;
+    const float* r1 = v1 + (size_t)b * C;
+    const float* r2 = v2 + (size_t)b * C;
+    double s = 0.0;
+    int guard = 0;
+    for (int c = threadIdx.x; c < C; c += DIR_TPB) {
+        const float a = r1[c], bb = r2[c];
+        s += (double)a;
+        guard |= (a <= 0.0f) || (bb < 0.0f);                 // exactly the reference's `.any()` tests (NaN compares false)
+    }
+    s = dir_wave_sum(s);
+    if ((threadIdx.x & (DIR_WAVE - 1)) == 0) wsum[threadIdx.x / DIR_WAVE] = s;
+    const int any_guard = __syncthreads_or(guard);
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIR_TPB / DIR_WAVE; ++i) tot += wsum[i];
+    const bool row_identity = (tot < 1e-10) || (guard_mode == 1 && any_guard);
+    for (int c = threadIdx.x; c < C; c += DIR_TPB) {
+        const float a = r1[c], bb = r2[c];
+        const bool untouched = row_identity || (guard_mode == 0 ? (a == 0.0f) : ((a <= 0.0f) || (bb < 0.0f)));
+        float out = -1.0f;
+        if (!untouched) {
+            float q = bb / a;
+            q = (q < clip_min) ? clip_min : ((q > clip_max) ? clip_max : q);
+            out = sqrtf(q);
+        }
+        scale[(size_t)b * C + c] = out;
+    }
+}
+
+extern "C" int dir_fds_prepare_scale_ex(const float* v1, const float* v2, int nb, int C, float clip_min, float clip_max,
+                                        int guard_mode, float* scale, dir_stream_t stream) {
+    DIR_RETURN_IF(!v1 || !v2 || !scale || nb <= 0 || C <= 0 || guard_mode < 0 || guard_mode > 2, DIR_EINVAL);
+    hipLaunchKernelGGL(fds_prepare_scale_ex_kernel, dim3(nb), dim3(DIR_TPB), 0, dir_s(stream), v1, v2, C, clip_min, clip_max,
+                       guard_mode, scale);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}

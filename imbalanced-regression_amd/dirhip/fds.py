@@ -69,6 +69,9 @@ def merge_stats_across_ranks(count, mean, m2, group=None):
 
 
 class FDS(nn.Module):
+    # calibration constants of this variant (utils.py:97: clip [0.1, 10], columns with v1 == 0 untouched)
+    CLIP = (0.1, 10.0)
+    GUARD_MODE = 0
 
     def __init__(self, feature_dim, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
                  kernel='gaussian', ks=5, sigma=2, momentum=0.9):
@@ -130,7 +133,8 @@ class FDS(nn.Module):
         v1, v2 = self.running_var_last_epoch, self.smoothed_var_last_epoch
         key = (v1.data_ptr(), v1._version, v2.data_ptr(), v2._version)
         if self._scale is None or key != self._scale_key:
-            self._scale = ops.prepare_scale(v1.contiguous(), v2.contiguous(), 0.1, 10.0)
+            self._scale = ops.prepare_scale(v1.contiguous(), v2.contiguous(), self.CLIP[0], self.CLIP[1],
+                                            guard_mode=self.GUARD_MODE)
             self._scale_key = key
         return self._scale
 
@@ -242,5 +246,8 @@ class FDS(nn.Module):
         labels = L.require_device_tensor(labels.contiguous(), torch.float32, "labels")
         assert features.dim() == 2 and features.size(1) == self.feature_dim
         assert labels.numel() == features.size(0)
+        return self._smooth_apply(features, labels)
+
+    def _smooth_apply(self, features, labels):
         return _SmoothFn.apply(features, labels, self.running_mean_last_epoch, self._scale_table(),
                                self.smoothed_mean_last_epoch, self.bucket_start, self.bucket_num)

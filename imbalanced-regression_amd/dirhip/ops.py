@@ -46,6 +46,22 @@ def bin_index(labels, bucket_start, bucket_num):
     return bins, flags
 
 
+def bin_edges(labels, edges, bucket_start, bucket_num):
+    """STS-B variant: labels [n] f32, edges [nedges] f32 (device) -> table rows [n] int32 (-1 = skipped)."""
+    labels = L.require_device_tensor(labels, f32, "labels")
+    edges = L.require_device_tensor(edges, f32, "edges")
+    bins = torch.empty(labels.numel(), dtype=i32, device=labels.device)
+    L.check(L.lib().dir_fds_bin_edges(L.ptr(labels), labels.numel(), L.ptr(edges), edges.numel(), bucket_start, bucket_num,
+                                      L.ptr(bins), L.stream_ptr(labels.device)), "dir_fds_bin_edges")
+    return bins
+
+
+def fill_empty_buckets(count, running_mean, running_var):
+    nb, c = running_mean.shape
+    L.check(L.lib().dir_fds_fill_empty_buckets(L.ptr(count), nb, c, L.ptr(running_mean), L.ptr(running_var),
+                                               L.stream_ptr(running_mean.device)), "dir_fds_fill_empty_buckets")
+
+
 # ---- K2 -------------------------------------------------------------------------------------------
 def scatter_stats(feats, bins, nb):
     """feats [n, C] f32, bins [n] int32 -> count [nb], mean [nb, C], m2 [nb, C] (all f64)."""
@@ -89,13 +105,18 @@ def smooth_bins(mean, var, window):
 
 
 # ---- K5a / K5 / K6 --------------------------------------------------------------------------------
-def prepare_scale(v1, v2, clip_min=0.1, clip_max=10.0, out=None):
+def prepare_scale(v1, v2, clip_min=0.1, clip_max=10.0, out=None, guard_mode=0):
+    """guard_mode 0: age variant (untouched where v1 == 0); 1: STS-B / NYUD2 (untouched where v1 <= 0 or v2 < 0)."""
     v1 = L.require_device_tensor(v1, f32, "v1")
     v2 = L.require_device_tensor(v2, f32, "v2")
     nb, c = v1.shape
     scale = torch.empty_like(v1) if out is None else out
-    L.check(L.lib().dir_fds_prepare_scale(L.ptr(v1), L.ptr(v2), nb, c, clip_min, clip_max, L.ptr(scale),
-                                          L.stream_ptr(v1.device)), "dir_fds_prepare_scale")
+    if guard_mode == 0:
+        L.check(L.lib().dir_fds_prepare_scale(L.ptr(v1), L.ptr(v2), nb, c, clip_min, clip_max, L.ptr(scale),
+                                              L.stream_ptr(v1.device)), "dir_fds_prepare_scale")
+    else:
+        L.check(L.lib().dir_fds_prepare_scale_ex(L.ptr(v1), L.ptr(v2), nb, c, clip_min, clip_max, guard_mode, L.ptr(scale),
+                                                 L.stream_ptr(v1.device)), "dir_fds_prepare_scale_ex")
     return scale
 
 

@@ -259,6 +259,28 @@ int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W
 int dir_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);
 int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, dir_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * STS-B-DIR FDS variant (sts-b-dir/fds.py, sts-b-dir/util.py:63-73) — SURVEY.md §8f-2.  Same scatter / finalize /
+ * smooth / calibrate kernels as the age variant, plus:
+ *   dir_fds_bin_edges:          bin = bucket_num-1 if label == edges[nedges-1], else
+ *                               max((first i with edges[i] > label) - 1, bucket_start)   (fds.py:51-57); output is the
+ *                               table row (bin - bucket_start), -1 where the reference raises (label > last edge, NaN).
+ *                               edges: device f32 [nedges] = np.histogram(bins=bucket_num, range=(0,5)) edges.
+ *   dir_fds_fill_empty_buckets: buckets with count == 0 in this update take (left+right)/2 (ends: the neighbour),
+ *                               in increasing bucket order (fds.py:112-125).
+ *   dir_fds_prepare_scale_ex:   guard_mode 0 = the age variant (column untouched when v1 == 0);
+ *                               guard_mode 1 = util.py:66-70 as it EXECUTES on torch >= 1.2: `(v1 > 0) + (v2 >= 0)` is a
+ *                               bool (logical or) and `== 2` is never true, so a row with ANY column v1 <= 0 or v2 < 0 is
+ *                               returned unchanged as a whole;
+ *                               guard_mode 2 = the intent (torch 0.4.1 semantics): only those columns stay untouched.
+ */
+int dir_fds_bin_edges(const float* labels, int n, const float* edges, int nedges, int bucket_start,
+                      int bucket_num, int32_t* bins, dir_stream_t stream);
+int dir_fds_fill_empty_buckets(const double* count, int nb, int C, float* running_mean, float* running_var,
+                               dir_stream_t stream);
+int dir_fds_prepare_scale_ex(const float* v1, const float* v2, int nb, int C, float clip_min, float clip_max,
+                             int guard_mode, float* scale, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

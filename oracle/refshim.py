@@ -100,3 +100,29 @@ def prepare_weights(labels, subdir="imdb-wiki-dir", **kw):
     obj = cls.__new__(cls)
     obj.df = pd.DataFrame({"age": labels})
     return obj._prepare_weights(**kw)
+
+
+def load_stsb():
+    """Reference sts-b-dir FDS pieces only (fds.py + util.py; both import nothing beyond numpy/scipy/torch)."""
+    if "sts-b" in _CACHE:
+        return _CACHE["sts-b"]
+    base = os.path.join(REFERENCE_ROOT, "sts-b-dir")
+    if not os.path.isfile(os.path.join(base, "fds.py")):
+        raise RuntimeError("reference sts-b-dir not present")
+    saved = {n: sys.modules.get(n) for n in ("util", "fds")}
+    ns = types.SimpleNamespace()
+    try:
+        for n in ("util", "fds"):
+            spec = importlib.util.spec_from_file_location(n, os.path.join(base, n + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[n] = mod
+            spec.loader.exec_module(mod)
+            setattr(ns, n, mod)
+    finally:
+        for n, old in saved.items():
+            if old is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = old
+    _CACHE["sts-b"] = ns
+    return ns

@@ -340,6 +340,60 @@ def gen_train_trajectory():
     print("trajectory losses", out["a_ref_losses"], out["b_ref_losses"])
 
 
+def gen_stsb():
+    """STS-B FDS variant (sts-b-dir/fds.py + util.py:63-73): state-machine trace with empty buckets (incl. both ends and a
+    run of consecutive empties), labels 0 / 5 / <0.1, and calibrate_mean_var cases with the v1 <= 0 / v2 < 0 guards."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    ref = refshim.load_stsb()
+    rng = np.random.default_rng(77)
+    kw = dict(feature_dim=24, bucket_num=50, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9)
+    with refshim.cuda_identity():
+        R = ref.fds.FDS(**kw)
+    out = {"kw": np.array(json.dumps(kw))}
+    n = 260
+    for epoch in range(4):
+        labels = np.round(np.clip(rng.normal(2.6, 1.1, n), 0, 5), 3).astype(np.float32)
+        labels[:6] = [0.0, 5.0, 4.95, 0.0999, 0.1, 2.5]
+        labels[(labels >= 1.0) & (labels < 1.3)] = 1.35          # buckets 10..12 empty (a run)
+        if epoch % 2 == 0:
+            labels[labels < 0.1] = 0.15                           # bucket 0 empty on even epochs
+            labels[labels >= 4.9] = 4.85                          # bucket 49 empty on even epochs
+        feats = (np.abs(rng.normal(0, 1, (n, 24))) * 0.5 + 0.1 * labels[:, None]).astype(np.float32)
+        feats[:, 3] = 0.0
+        xb, lb = feats[:40].copy(), labels[:40, None].copy()
+        gy = rng.normal(0, 1, xb.shape).astype(np.float32)
+        xt = torch.tensor(xb, requires_grad=True)
+        with refshim.cuda_identity():
+            yt = R.smooth(xt.clone(), torch.tensor(lb), epoch)
+        yt.backward(torch.tensor(gy))
+        out.update({f"e{epoch}_in_x": xb, f"e{epoch}_in_labels_b": lb, f"e{epoch}_in_gy": gy,
+                    f"e{epoch}_ref_smooth": yt.detach().numpy().copy(), f"e{epoch}_ref_gx": xt.grad.numpy().copy()})
+        for k in BUFFERS:
+            out[f"e{epoch}_pre_{k}"] = getattr(R, k).detach().numpy().copy()
+        with refshim.cuda_identity():
+            R.update_last_epoch_stats(epoch)
+            R.update_running_stats(torch.tensor(feats), torch.tensor(labels), epoch)
+        out[f"e{epoch}_in_feats"], out[f"e{epoch}_in_labels"] = feats, labels
+        out[f"e{epoch}_ref_buckets"] = np.array([R._get_bucket_idx(l) for l in labels])
+        for k in BUFFERS:
+            out[f"e{epoch}_post_{k}"] = getattr(R, k).detach().numpy().copy()
+    save("fds_trace_stsb.npz", **out)
+    c = 32
+    m1, m2 = rng.normal(0, 1, c).astype(np.float32), rng.normal(0, 1, c).astype(np.float32)
+    v1, v2 = rng.uniform(0.01, 2, c).astype(np.float32), rng.uniform(0.01, 2, c).astype(np.float32)
+    v1g, v2g = v1.copy(), v2.copy()
+    v1g[[1, 7]] = [0.0, -0.5]; v2g[[4, 9]] = [-1e-3, 0.0]
+    cases = [(m1, v1, m2, v2, 0.5, 2.0), (m1, v1g, m2, v2g, 0.5, 2.0), (m1, np.full(c, 1e-13, np.float32), m2, v2, 0.5, 2.0),
+             (m1, v1, m2, v2 * np.float32(50), 0.5, 2.0), (m1, v1g, m2, v2g, 0.2, 5.0)]
+    o2 = {"n": np.array(len(cases))}
+    for i, (a, b, cc, d, lo, hi) in enumerate(cases):
+        x = rng.normal(0, 1, (7, c)).astype(np.float32)
+        y = ref.util.calibrate_mean_var(torch.tensor(x.copy()), torch.tensor(a), torch.tensor(b), torch.tensor(cc), torch.tensor(d), lo, hi)
+        o2.update({f"in_x_{i}": x, f"in_m1_{i}": a, f"in_v1_{i}": b, f"in_m2_{i}": cc, f"in_v2_{i}": d, f"clip_{i}": np.array([lo, hi]), f"ref_y_{i}": y.numpy()})
+    save("calibrate_stsb.npz", **o2)
+
+
 def main():
     ref = refshim.load("imdb-wiki-dir")
     gen_windows(ref)
@@ -350,6 +404,7 @@ def main():
     gen_losses(ref)
     gen_resnet()
     gen_train_trajectory()
+    gen_stsb()
     manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
                 "agedb_sqrtinv_lds_g52_sha256_prefix": sha,
                 "files": sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))}

@@ -317,3 +317,91 @@ def test_full_size_smooth_identity_and_linearity():
     assert_close(sab.cpu().numpy(), (sa + sb).cpu().numpy(), rtol=1e-5, atol_scale=1e-6)
     ones, _ = ops.smooth_bins(torch.full((100, 2048), 3.0, device="cuda"), b, w)
     assert_close(ones.cpu().numpy(), np.full((100, 2048), 3.0), rtol=1e-6, atol_scale=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# STS-B FDS variant: histogram-edge buckets, clip [0.5, 2] with v1 <= 0 / v2 < 0 guards,
+# empty-bucket fill — vs the reference's own outputs (golden) and the oracle
+# ---------------------------------------------------------------------------------------------------
+def test_stsb_fds_state_machine_vs_reference_golden(golden):
+    from dirhip.fds_stsb import FDS as StsbFDS
+    from oracle import fds_stsb_oracle as so
+    g = golden("fds_trace_stsb.npz")
+    kw = json.loads(str(g["kw"]))
+    F = StsbFDS(**kw).cuda()
+    O = so.FDSStsbOracle(**kw)
+    for epoch in range(4):
+        bins = F._bins(dev(g[f"e{epoch}_in_labels"])).cpu().numpy()
+        assert np.array_equal(bins, g[f"e{epoch}_ref_buckets"] - kw["bucket_start"])           # bucket indices: bit-exact
+        P = StsbFDS(**kw).cuda()
+        load_tables(P, g, f"e{epoch}_pre_")
+        x = dev(g[f"e{epoch}_in_x"]).requires_grad_(True)
+        xin = x.clone()
+        y = P.smooth(xin, dev(g[f"e{epoch}_in_labels_b"]), epoch)
+        assert y.data_ptr() == xin.data_ptr()
+        y.backward(dev(g[f"e{epoch}_in_gy"]))
+        assert_close(y.detach().cpu().numpy(), g[f"e{epoch}_ref_smooth"], rtol=2e-7, atol_scale=2e-7, msg=f"smooth e{epoch}")
+        assert_close(x.grad.cpu().numpy(), g[f"e{epoch}_ref_gx"], rtol=2e-7, atol_scale=2e-7, msg=f"grad e{epoch}")
+        F.update_last_epoch_stats(epoch)
+        O.update_last_epoch_stats(epoch)
+        F.update_running_stats(dev(g[f"e{epoch}_in_feats"]), dev(g[f"e{epoch}_in_labels"]), epoch)
+        O.update_running_stats(g[f"e{epoch}_in_feats"], g[f"e{epoch}_in_labels"], epoch)
+        for k in BUFFERS:
+            got = getattr(F, k).cpu().numpy()
+            assert_close(got, g[f"e{epoch}_post_{k}"], msg=f"post e{epoch} {k} vs reference")
+            assert_close(got, getattr(O, k), msg=f"post e{epoch} {k} vs oracle")
+        assert np.array_equal(F.num_samples_tracked.cpu().numpy(), g[f"e{epoch}_post_num_samples_tracked"])
+
+
+def test_stsb_calibrate_mean_var(golden):
+    from dirhip.fds_stsb import calibrate_mean_var
+    from oracle import fds_stsb_oracle as so
+    g = golden("calibrate_stsb.npz")
+    for i in range(int(g["n"])):
+        lo, hi = (float(v) for v in g[f"clip_{i}"])
+        y = calibrate_mean_var(dev(g[f"in_x_{i}"]), dev(g[f"in_m1_{i}"]), dev(g[f"in_v1_{i}"]), dev(g[f"in_m2_{i}"]), dev(g[f"in_v2_{i}"]), lo, hi)
+        assert_close(y.cpu().numpy(), g[f"ref_y_{i}"], rtol=2e-7, atol_scale=2e-7, msg=f"case {i}")
+        yo = so.calibrate_mean_var(g[f"in_x_{i}"].copy(), g[f"in_m1_{i}"], g[f"in_v1_{i}"], g[f"in_m2_{i}"], g[f"in_v2_{i}"], lo, hi)
+        assert np.array_equal(y.cpu().numpy(), yo)
+
+
+def test_stsb_full_size_shapes():
+    """BASELINE configs[4] shapes: features [128, 12000], 50 buckets on [0, 5]: smooth is the identity on fresh tables,
+    bucket indices equal the oracle's for random scores, statistics are bit-reproducible."""
+    from dirhip.fds_stsb import FDS as StsbFDS
+    from oracle import fds_stsb_oracle as so
+    rng = np.random.default_rng(8)
+    F = StsbFDS(12000).cuda()
+    labels = np.round(rng.uniform(0, 5, 128), 3).astype(np.float32)
+    labels[:3] = [0.0, 5.0, 2.5]
+    x = torch.randn(128, 12000, device="cuda")
+    assert torch.equal(F.smooth(x.clone(), dev(labels[:, None]), 1), x)
+    assert np.array_equal(F._bins(dev(labels)).cpu().numpy(), so.bucket_idx(labels, 0, 50))
+    feats = torch.randn(5249, 12000, device="cuda").abs_()
+    lab = dev(np.round(rng.uniform(0, 5, 5249), 3).astype(np.float32))
+    a = F.local_stats(feats, lab)
+    b = F.local_stats(feats, lab)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    F.update_last_epoch_stats(0)
+    F.update_running_stats(feats, lab, 0)
+    assert float(F.num_samples_tracked.sum()) == 5249
+
+
+def test_stsb_guard_modes_vs_oracle():
+    """guard_mode 1 (reference as executed on torch >= 1.2: any guarded column -> whole row untouched) and guard_mode 2
+    (torch 0.4.1 / intended: only the guarded columns untouched) against the oracle, bit for bit."""
+    from dirhip import ops
+    from oracle import fds_stsb_oracle as so
+    rng = np.random.default_rng(12)
+    nb, c = 50, 12000
+    v1 = rng.uniform(0.01, 2, (nb, c)).astype(np.float32)
+    v2 = rng.uniform(0.01, 2, (nb, c)).astype(np.float32)
+    v1[3, ::11] = 0.0
+    v1[4, 5] = -0.25
+    v2[5, 7] = -1e-6
+    v1[6] = 1e-15
+    for mode, per_col in ((1, False), (2, True)):
+        s = ops.prepare_scale(dev(v1), dev(v2), 0.5, 2.0, guard_mode=mode).cpu().numpy()
+        want = np.stack([so.calibrate_scale(v1[b], v2[b], 0.5, 2.0, per_column_guard=per_col) for b in range(nb)])
+        assert np.array_equal(s, want), mode

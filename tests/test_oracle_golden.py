@@ -141,3 +141,29 @@ def test_oracle_vs_live_reference_random():
             O.update_running_stats(feats, labels, epoch)
             for k in BUFFERS:
                 assert_close(getattr(O, k), getattr(R, k).numpy(), msg=f"{trial} {epoch} {k}")
+
+
+# ---- STS-B FDS variant -----------------------------------------------------------------
+def test_stsb_oracle_state_machine(golden):
+    from oracle import fds_stsb_oracle as so
+    g = golden("fds_trace_stsb.npz")
+    kw = json.loads(str(g["kw"]))
+    O = so.FDSStsbOracle(**kw)
+    for epoch in range(4):
+        assert np.array_equal(so.bucket_idx(g[f"e{epoch}_in_labels"], kw["bucket_start"], kw["bucket_num"]), g[f"e{epoch}_ref_buckets"])
+        y = O.smooth(g[f"e{epoch}_in_x"].copy(), g[f"e{epoch}_in_labels_b"], epoch)
+        assert_close(y, g[f"e{epoch}_ref_smooth"], msg=f"smooth e{epoch}")
+        assert_close(O.smooth_grad(g[f"e{epoch}_in_gy"], g[f"e{epoch}_in_labels_b"], epoch), g[f"e{epoch}_ref_gx"], msg=f"grad e{epoch}")
+        O.update_last_epoch_stats(epoch)
+        O.update_running_stats(g[f"e{epoch}_in_feats"], g[f"e{epoch}_in_labels"], epoch)
+        for k in BUFFERS:
+            assert_close(getattr(O, k), g[f"e{epoch}_post_{k}"], msg=f"post e{epoch} {k}")
+
+
+def test_stsb_calibrate_oracle(golden):
+    from oracle import fds_stsb_oracle as so
+    g = golden("calibrate_stsb.npz")
+    for i in range(int(g["n"])):
+        lo, hi = g[f"clip_{i}"]
+        y = so.calibrate_mean_var(g[f"in_x_{i}"].copy(), g[f"in_m1_{i}"], g[f"in_v1_{i}"], g[f"in_m2_{i}"], g[f"in_v2_{i}"], lo, hi)
+        assert_close(y, g[f"ref_y_{i}"], rtol=2e-7, atol_scale=2e-7, msg=f"case {i}")
