@@ -260,6 +260,58 @@ fds_piece_sums_kernel(const float* __restrict__ feats, int C,
     for (int j = 0; j < VEC; ++j) { o1[j] = s1[j]; o2[j] = s2[j]; }
 }
 
+
+// Narrow feature rows (C <= 512, e.g. the dense NYUD2 variant's C = 128): one row occupies only C/4 lanes, so a
+// workgroup walks RL = 256 / (C/4) rows of the piece at a time (row lanes) and the lane partials are combined in LDS
+// in lane order (deterministic) before the piece partial is written.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_piece_sums_narrow_kernel(const float* __restrict__ feats, int C, int tpr,
+                             const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets,
+                             const int32_t* __restrict__ npieces, const int32_t* __restrict__ piece_bin,
+                             const int32_t* __restrict__ piece_p0, const int32_t* __restrict__ piece_p1,
+                             double* __restrict__ partials) {
+    __shared__ double sh[2][DIR_TPB * 4];
+    const int k = blockIdx.x;
+    if (k >= *npieces) return;
+    const int rl = DIR_TPB / tpr;                       // row lanes
+    const int t = threadIdx.x, tc = t % tpr, tl = t / tpr;
+    const int col = tc * 4;
+    const int b = piece_bin[k], p0 = piece_p0[k], p1 = piece_p1[k];
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (tl < rl) {
+        const float4 kv = *reinterpret_cast<const float4*>(feats + (size_t)perm[offsets[b]] * C + col);
+        const double kd[4] = {(double)kv.x, (double)kv.y, (double)kv.z, (double)kv.w};
+        int p = p0 + tl;
+        for (; p + 3 * rl < p1; p += 4 * rl) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(feats + (size_t)perm[p + u * rl] * C + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d0 = (double)v[u].x - kd[0], d1 = (double)v[u].y - kd[1], d2 = (double)v[u].z - kd[2], d3 = (double)v[u].w - kd[3];
+                s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
+            }
+        }
+        for (; p < p1; p += rl) {
+            const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)perm[p] * C + col);
+            const double d0 = (double)v.x - kd[0], d1 = (double)v.y - kd[1], d2 = (double)v.z - kd[2], d3 = (double)v.w - kd[3];
+            s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[0][t * 4 + j] = s1[j]; sh[1][t * 4 + j] = s2[j]; }
+    __syncthreads();
+    if (tl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = 0.0, q = 0.0;
+            for (int l = 0; l < rl; ++l) { a += sh[0][(l * tpr + tc) * 4 + j]; q += sh[1][(l * tpr + tc) * 4 + j]; }
+            partials[((size_t)k * 2 + 0) * C + col + j] = a;
+            partials[((size_t)k * 2 + 1) * C + col + j] = q;
+        }
+    }
+}
+
 // C: combine the pieces of each bin in index order.
 __global__ void __launch_bounds__(DIR_TPB)
 fds_combine_kernel(const float* __restrict__ feats, int C, int nb,
@@ -316,7 +368,11 @@ extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t
                        bins, n, nb, w.tile_hist, w.offsets, w.perm);
     DIR_LAUNCH_CHECK();
     const bool vec4 = (C % 4 == 0) && dir_aligned16(feats);
-    if (vec4) {
+    const int tpr = C / 4;
+    if (vec4 && tpr <= 128 && DIR_TPB % tpr == 0) {
+        hipLaunchKernelGGL(fds_piece_sums_narrow_kernel, dim3(w.maxpieces), dim3(DIR_TPB), 0, s, f, C, tpr, w.perm, w.offsets,
+                           w.npieces, w.piece_bin, w.piece_p0, w.piece_p1, w.partials);
+    } else if (vec4) {
         dim3 grid(w.maxpieces, dir_cdiv(C, DIR_TPB * 4));
         hipLaunchKernelGGL(fds_piece_sums_kernel<4>, grid, dim3(DIR_TPB), 0, s, f, C, w.perm, w.offsets,
                            w.npieces, w.piece_bin, w.piece_p0, w.piece_p1, w.partials);
@@ -532,6 +588,42 @@ fds_calibrate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
     }
 }
 
+// Narrow rows (C <= 512): several rows per workgroup, per-thread bin lookup (dense NYUD2 features: every pixel has
+// its own depth bucket). BWD = false: x = (x - m1) * s + m2 in place; BWD = true: dx = dy * s.
+template <bool BWD>
+__global__ void __launch_bounds__(DIR_TPB)
+fds_calibrate_narrow_kernel(float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ bins,
+                            long long B, int C, int tpr, const float* __restrict__ m1, const float* __restrict__ scale,
+                            const float* __restrict__ m2) {
+    const int rpb = DIR_TPB / tpr;
+    const int t = threadIdx.x, tc = t % tpr, tl = t / tpr;
+    if (tl >= rpb) return;
+    const int col = tc * 4;
+    for (long long row = (long long)blockIdx.x * rpb + tl; row < B; row += (long long)gridDim.x * rpb) {
+        const int bin = bins[row];
+        const size_t xo = (size_t)row * C + col;
+        if (BWD) {
+            float4 g = *reinterpret_cast<const float4*>(dy + xo);
+            if (bin >= 0) {
+                const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)bin * C + col);
+                g.x = sc.x < 0.0f ? g.x : g.x * sc.x; g.y = sc.y < 0.0f ? g.y : g.y * sc.y;
+                g.z = sc.z < 0.0f ? g.z : g.z * sc.z; g.w = sc.w < 0.0f ? g.w : g.w * sc.w;
+            }
+            *reinterpret_cast<float4*>(x + xo) = g;
+        } else {
+            if (bin < 0) continue;
+            const size_t to = (size_t)bin * C + col;
+            float4 v = *reinterpret_cast<float4*>(x + xo);
+            const float4 a = *reinterpret_cast<const float4*>(m1 + to);
+            const float4 sc = *reinterpret_cast<const float4*>(scale + to);
+            const float4 c = *reinterpret_cast<const float4*>(m2 + to);
+            v.x = calib1(v.x, a.x, sc.x, c.x); v.y = calib1(v.y, a.y, sc.y, c.y);
+            v.z = calib1(v.z, a.z, sc.z, c.z); v.w = calib1(v.w, a.w, sc.w, c.w);
+            *reinterpret_cast<float4*>(x + xo) = v;
+        }
+    }
+}
+
 static bool vec4_ok(int C, const void* a, const void* b, const void* c, const void* d) {
     return (C % 4 == 0) && dir_aligned16(a) && dir_aligned16(b) && dir_aligned16(c) && dir_aligned16(d);
 }
@@ -543,7 +635,12 @@ extern "C" int dir_fds_calibrate_fwd(void* x_inout, int dtype, const int32_t* bi
     DIR_RETURN_IF(!x_inout || !bins || !m1 || !scale || !m2, DIR_EINVAL);
     DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
     float* x = static_cast<float*>(x_inout);
-    if (vec4_ok(C, x, m1, scale, m2)) {
+    if (vec4_ok(C, x, m1, scale, m2) && C / 4 <= 128 && DIR_TPB % (C / 4) == 0) {
+        const int tpr = C / 4, rpb = DIR_TPB / tpr;
+        int grid = dir_cdiv(B, rpb); if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(fds_calibrate_narrow_kernel<false>, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), x, nullptr, bins,
+                           (long long)B, C, tpr, m1, scale, m2);
+    } else if (vec4_ok(C, x, m1, scale, m2)) {
         hipLaunchKernelGGL((fds_calibrate_fwd_kernel<4, false>), dim3(B, dir_cdiv(C, DIR_TPB * 4)), dim3(DIR_TPB), 0,
                            dir_s(stream), x, bins, nullptr, B, C, 0.f, 0.f, m1, scale, m2, nullptr);
     } else {
@@ -562,7 +659,12 @@ extern "C" int dir_fds_calibrate_bwd(const void* dy, void* dx, int dtype, const 
     DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
     const float* g = static_cast<const float*>(dy);
     float* o = static_cast<float*>(dx);
-    if (vec4_ok(C, g, o, scale, scale)) {
+    if (vec4_ok(C, g, o, scale, scale) && C / 4 <= 128 && DIR_TPB % (C / 4) == 0) {
+        const int tpr = C / 4, rpb = DIR_TPB / tpr;
+        int grid = dir_cdiv(B, rpb); if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(fds_calibrate_narrow_kernel<true>, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), o, g, bins,
+                           (long long)B, C, tpr, nullptr, scale, nullptr);
+    } else if (vec4_ok(C, g, o, scale, scale)) {
         hipLaunchKernelGGL(fds_calibrate_bwd_kernel<4>, dim3(B, dir_cdiv(C, DIR_TPB * 4)), dim3(DIR_TPB), 0,
                            dir_s(stream), g, o, bins, C, scale);
     } else {
@@ -714,6 +816,39 @@ extern "C" int dir_fds_prepare_scale_ex(const float* v1, const float* v2, int nb
     DIR_RETURN_IF(!v1 || !v2 || !scale || nb <= 0 || C <= 0 || guard_mode < 0 || guard_mode > 2, DIR_EINVAL);
     hipLaunchKernelGGL(fds_prepare_scale_ex_kernel, dim3(nb), dim3(DIR_TPB), 0, dir_s(stream), v1, v2, C, clip_min, clip_max,
                        guard_mode, scale);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+
+// =============================================================================================
+// NYUD2-DIR dense variant (nyud2-dir/models/fds.py:51-53, :138-139): bucket = clamp(int(label * 10), start, num - 1)
+// =============================================================================================
+__global__ void __launch_bounds__(DIR_TPB)
+fds_bin_scaled_kernel(const float* __restrict__ labels, long long n, float mult, int bucket_start, int bucket_num,
+                      int32_t* __restrict__ bins) {
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (long long)gridDim.x * DIR_TPB) {
+        const float l = labels[i];
+        int b = -1;
+        if (l == l) {                                       // int(NaN) raises in the reference
+            const float v = l * mult;                       // float32 product, then truncation (fds.py:52)
+            int k = (v >= 2147483520.0f) ? 2147483647 : ((v <= -2147483520.0f) ? -2147483647 : (int)v);
+            if (k > bucket_num - 1) k = bucket_num - 1;
+            if (k < bucket_start) k = bucket_start;
+            b = k - bucket_start;
+        }
+        bins[i] = b;
+    }
+}
+
+extern "C" int dir_fds_bin_scaled(const float* labels, long long n, float mult, int bucket_start, int bucket_num,
+                                  int32_t* bins, dir_stream_t stream) {
+    DIR_RETURN_IF(!labels || !bins || n < 0, DIR_EINVAL);
+    DIR_RETURN_IF(check_buckets(bucket_start, bucket_num), DIR_EINVAL);
+    if (n == 0) return DIR_OK;
+    int grid = dir_cdiv(n, DIR_TPB); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fds_bin_scaled_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), labels, n, mult, bucket_start,
+                       bucket_num, bins);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "dir_fds_bin_edges": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dir_fds_fill_empty_buckets": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_fds_prepare_scale_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "dir_fds_bin_scaled": (c_int, [c_void_p, ctypes.c_longlong, c_float, c_int, c_int, c_void_p, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 

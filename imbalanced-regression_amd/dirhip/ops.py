@@ -56,6 +56,15 @@ def bin_edges(labels, edges, bucket_start, bucket_num):
     return bins
 
 
+def bin_scaled(labels, mult, bucket_start, bucket_num):
+    """NYUD2 variant: labels [n] f32 -> table rows clamp(int(label * mult), start, num - 1) - start (int32)."""
+    labels = L.require_device_tensor(labels, f32, "labels")
+    bins = torch.empty(labels.numel(), dtype=i32, device=labels.device)
+    L.check(L.lib().dir_fds_bin_scaled(L.ptr(labels), labels.numel(), float(mult), bucket_start, bucket_num, L.ptr(bins),
+                                       L.stream_ptr(labels.device)), "dir_fds_bin_scaled")
+    return bins
+
+
 def fill_empty_buckets(count, running_mean, running_var):
     nb, c = running_mean.shape
     L.check(L.lib().dir_fds_fill_empty_buckets(L.ptr(count), nb, c, L.ptr(running_mean), L.ptr(running_var),

@@ -281,6 +281,14 @@ int dir_fds_fill_empty_buckets(const double* count, int nb, int C, float* runnin
 int dir_fds_prepare_scale_ex(const float* v1, const float* v2, int nb, int C, float clip_min, float clip_max,
                              int guard_mode, float* scale, dir_stream_t stream);
 
+/* NYUD2-DIR dense FDS variant (nyud2-dir/models/fds.py, nyud2-dir/util.py:151-162) — SURVEY.md §8f-1: per-pixel buckets
+ * bucket = clamp(int(depth * mult), bucket_start, bucket_num - 1) (float32 product, truncation; fds.py:51-53,138-139);
+ * output = table row (bucket - bucket_start), -1 for NaN.  The [B,128,H,W] feature maps are handled as [B*H*W, 128] rows
+ * by the shared kernels (narrow-row paths inside dir_fds_scatter_stats / dir_fds_calibrate_*), calibration uses
+ * dir_fds_prepare_scale_ex with clip [0.2, 5]. */
+int dir_fds_bin_scaled(const float* labels, long long n, float mult, int bucket_start, int bucket_num,
+                       int32_t* bins, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,51 @@ def load_stsb():
                 sys.modules[n] = old
     _CACHE["sts-b"] = ns
     return ns
+
+
+@contextlib.contextmanager
+def device_transfer_clones():
+    """NYUD2 shim: ``Tensor.cuda()`` / ``Tensor.cpu()`` return a NEW tensor (clone), like a real device transfer does
+    (nyud2-dir/models/fds.py:88-96 relies on it: the re-created running buffers stop aliasing the *_last_epoch ones), and
+    ``np.bool`` (removed in numpy >= 1.24, used at fds.py:110) is restored for the duration."""
+    import numpy as np
+    import torch
+    t_cuda, t_cpu, m_cuda = torch.Tensor.cuda, torch.Tensor.cpu, torch.nn.Module.cuda
+    had_bool = hasattr(np, "bool")
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    if not had_bool:
+        np.bool = bool
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda, torch.Tensor.cpu, torch.nn.Module.cuda = t_cuda, t_cpu, m_cuda
+        if not had_bool:
+            del np.bool
+
+
+def load_nyud2():
+    """Reference nyud2-dir FDS pieces only (models/fds.py + util.py)."""
+    if "nyud2" in _CACHE:
+        return _CACHE["nyud2"]
+    base = os.path.join(REFERENCE_ROOT, "nyud2-dir")
+    if not os.path.isfile(os.path.join(base, "models", "fds.py")):
+        raise RuntimeError("reference nyud2-dir not present")
+    saved = {n: sys.modules.get(n) for n in ("util", "fds")}
+    ns = types.SimpleNamespace()
+    try:
+        for n, rel in (("util", "util.py"), ("fds", os.path.join("models", "fds.py"))):
+            spec = importlib.util.spec_from_file_location(n, os.path.join(base, rel))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[n] = mod
+            spec.loader.exec_module(mod)
+            setattr(ns, n, mod)
+    finally:
+        for n, old in saved.items():
+            if old is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = old
+    _CACHE["nyud2"] = ns
+    return ns

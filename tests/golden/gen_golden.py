@@ -394,6 +394,44 @@ def gen_stsb():
     save("calibrate_stsb.npz", **o2)
 
 
+def gen_nyud2():
+    """NYUD2 dense FDS variant (nyud2-dir/models/fds.py + util.py:151-162): features [B,16,9,11], depth maps [B,1,9,11],
+    buckets clamp(int(10 d), 7, 29); run with device-transfer shims that create new tensors (alias breaking, like the
+    real .cpu()/.cuda() round trip) and np.bool restored."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    ref = refshim.load_nyud2()
+    rng = np.random.default_rng(91)
+    kw = dict(feature_dim=16, bucket_num=30, bucket_start=7, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9)
+    with refshim.device_transfer_clones():
+        R = ref.fds.FDS(**kw)
+    out = {"kw": np.array(json.dumps(kw))}
+    for epoch in range(4):
+        depth = rng.uniform(0.5, 3.4, (6, 1, 9, 11)).astype(np.float32)
+        depth[0, 0, 0, :4] = [0.7, 0.6999, 2.9, 3.3]                          # below start, at the edges, above num-1
+        feats = (np.abs(rng.normal(0, 1, (6, 16, 9, 11))) * 0.5 + 0.2 * depth).astype(np.float32)
+        if epoch >= 2:
+            feats[:, 3] = 0.0                                                   # zero-variance column -> guard branch
+        xb, lb = feats[:2].copy(), depth[:2].copy()
+        gy = rng.normal(0, 1, xb.shape).astype(np.float32)
+        xt = torch.tensor(xb, requires_grad=True)
+        with refshim.device_transfer_clones():
+            yt = R.smooth(xt * 1.0, torch.tensor(lb), epoch)
+        yt.backward(torch.tensor(gy))
+        out.update({f"e{epoch}_in_x": xb, f"e{epoch}_in_labels_b": lb, f"e{epoch}_in_gy": gy,
+                    f"e{epoch}_ref_smooth": yt.detach().numpy().copy(), f"e{epoch}_ref_gx": xt.grad.numpy().copy()})
+        for k in BUFFERS:
+            out[f"e{epoch}_pre_{k}"] = getattr(R, k).detach().numpy().copy()
+        with refshim.device_transfer_clones():
+            R.update_last_epoch_stats(epoch)
+            R.update_running_stats(torch.tensor(feats), torch.tensor(depth), epoch)
+        out[f"e{epoch}_in_feats"], out[f"e{epoch}_in_labels"] = feats, depth
+        out[f"e{epoch}_alias"] = np.array(R.running_mean_last_epoch is R.running_mean)
+        for k in BUFFERS:
+            out[f"e{epoch}_post_{k}"] = getattr(R, k).detach().numpy().copy()
+    save("fds_trace_nyud2.npz", **out)
+
+
 def main():
     ref = refshim.load("imdb-wiki-dir")
     gen_windows(ref)
@@ -405,6 +443,7 @@ def main():
     gen_resnet()
     gen_train_trajectory()
     gen_stsb()
+    gen_nyud2()
     manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
                 "agedb_sqrtinv_lds_g52_sha256_prefix": sha,
                 "files": sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))}

@@ -405,3 +405,69 @@ def test_stsb_guard_modes_vs_oracle():
         s = ops.prepare_scale(dev(v1), dev(v2), 0.5, 2.0, guard_mode=mode).cpu().numpy()
         want = np.stack([so.calibrate_scale(v1[b], v2[b], 0.5, 2.0, per_column_guard=per_col) for b in range(nb)])
         assert np.array_equal(s, want), mode
+
+
+# ---------------------------------------------------------------------------------------------------
+# NYUD2 dense FDS variant: per-pixel buckets, NCHW maps, clip [0.2, 5], not in place, snapshots
+# ---------------------------------------------------------------------------------------------------
+def test_nyud2_fds_state_machine_vs_reference_golden(golden):
+    from dirhip.fds_nyud2 import FDS as DenseFDS
+    from oracle import fds_nyud2_oracle as no
+    g = golden("fds_trace_nyud2.npz")
+    kw = json.loads(str(g["kw"]))
+    F = DenseFDS(**kw).cuda()
+    O = no.FDSNyud2Oracle(**kw)
+    for epoch in range(4):
+        bins = F._bins(dev(g[f"e{epoch}_in_labels"]).squeeze(1)).cpu().numpy()
+        assert np.array_equal(bins, no.bucket_idx(g[f"e{epoch}_in_labels"].reshape(-1), kw["bucket_start"], kw["bucket_num"]) - kw["bucket_start"])
+        P = DenseFDS(**kw).cuda()
+        load_tables(P, g, f"e{epoch}_pre_")
+        x = dev(g[f"e{epoch}_in_x"]).requires_grad_(True)
+        xin = x * 1.0
+        y = P.smooth(xin, dev(g[f"e{epoch}_in_labels_b"]), epoch)
+        assert y.shape == x.shape
+        assert torch.equal(xin.detach(), x.detach())                           # caller's tensor untouched (not in place)
+        if epoch >= kw["start_smooth"]:
+            y.backward(dev(g[f"e{epoch}_in_gy"]))
+            assert_close(x.grad.cpu().numpy(), g[f"e{epoch}_ref_gx"], rtol=2e-7, atol_scale=2e-7, msg=f"grad e{epoch}")
+        assert_close(y.detach().cpu().numpy(), g[f"e{epoch}_ref_smooth"], rtol=2e-7, atol_scale=2e-7, msg=f"smooth e{epoch}")
+        F.update_last_epoch_stats(epoch)
+        O.update_last_epoch_stats(epoch)
+        F.update_running_stats(dev(g[f"e{epoch}_in_feats"]), dev(g[f"e{epoch}_in_labels"]), epoch)
+        O.update_running_stats(g[f"e{epoch}_in_feats"], g[f"e{epoch}_in_labels"], epoch)
+        for k in BUFFERS:
+            got = getattr(F, k).cpu().numpy()
+            assert_close(got, g[f"e{epoch}_post_{k}"], msg=f"post e{epoch} {k} vs reference")
+            assert_close(got, getattr(O, k), msg=f"post e{epoch} {k} vs oracle")
+        assert (F.running_mean_last_epoch is F.running_mean) == bool(g[f"e{epoch}_alias"])
+        assert np.array_equal(F.num_samples_tracked.cpu().numpy(), g[f"e{epoch}_post_num_samples_tracked"])
+
+
+def test_nyud2_full_size_whiten_recolor_and_speed():
+    """BASELINE configs[3] shapes: features [32, 128, 114, 152] (284 MB), depth ~ U(0.7, 10): statistics -> calibrate
+    towards random targets -> re-measure (K-scaled bins, narrow-row scatter and calibrate paths at full size)."""
+    from dirhip import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    b, c, h, w = 32, 128, 114, 152
+    depth = torch.rand(b, 1, h, w, device="cuda", generator=g) * 9.3 + 0.7
+    feats = torch.rand(b, c, h, w, device="cuda", generator=g) * 0.5 + 0.05 * depth
+    rows = feats.permute(0, 2, 3, 1).contiguous().view(-1, c)
+    bins = ops.bin_scaled(depth.reshape(-1), 10.0, 7, 100)
+    assert int(bins.min()) == 0 and int(bins.max()) == 92
+    nb = 93
+    cnt, m1, m2s = ops.scatter_stats(rows, bins, nb)
+    assert float(cnt.sum()) == rows.shape[0]
+    v1 = m2s / (cnt - 1).clamp(min=1)[:, None]
+    tgt_m = torch.rand(nb, c, device="cuda", generator=g)
+    tgt_v = v1 * (0.5 + 1.5 * torch.rand(nb, c, device="cuda", generator=g))
+    scale = ops.prepare_scale(v1.float(), tgt_v.float(), 0.2, 5.0, guard_mode=1)
+    out = rows.clone()
+    ops.calibrate_fwd_(out, bins, m1.float(), scale, tgt_m.float())
+    cnt2, mean2, m22 = ops.scatter_stats(out, bins, nb)
+    assert torch.equal(cnt, cnt2)
+    assert_close(mean2.cpu().numpy(), tgt_m.double().cpu().numpy(), rtol=1e-5, atol_scale=1e-5)
+    assert_close((m22 / (cnt - 1).clamp(min=1)[:, None]).cpu().numpy(), tgt_v.float().double().cpu().numpy(), rtol=1e-5, atol_scale=1e-5)
+    # gradient path: dx = dy * scale
+    dy = torch.randn(rows.shape, device="cuda", generator=g)
+    dx = ops.calibrate_bwd(dy, bins, scale)
+    assert torch.equal(dx, dy * scale[bins.long()])

@@ -167,3 +167,22 @@ def test_stsb_calibrate_oracle(golden):
         lo, hi = g[f"clip_{i}"]
         y = so.calibrate_mean_var(g[f"in_x_{i}"].copy(), g[f"in_m1_{i}"], g[f"in_v1_{i}"], g[f"in_m2_{i}"], g[f"in_v2_{i}"], lo, hi)
         assert_close(y, g[f"ref_y_{i}"], rtol=2e-7, atol_scale=2e-7, msg=f"case {i}")
+
+
+# ---- NYUD2 dense FDS variant -------------------------------------------------------------
+def test_nyud2_oracle_state_machine(golden):
+    from oracle import fds_nyud2_oracle as no
+    g = golden("fds_trace_nyud2.npz")
+    kw = json.loads(str(g["kw"]))
+    O = no.FDSNyud2Oracle(**kw)
+    for epoch in range(4):
+        xin = g[f"e{epoch}_in_x"].copy()
+        y = O.smooth(xin, g[f"e{epoch}_in_labels_b"], epoch)
+        assert np.array_equal(xin, g[f"e{epoch}_in_x"])                       # not in place
+        assert_close(y, g[f"e{epoch}_ref_smooth"], msg=f"smooth e{epoch}")
+        assert_close(O.smooth_grad(g[f"e{epoch}_in_gy"], g[f"e{epoch}_in_labels_b"], epoch), g[f"e{epoch}_ref_gx"], msg=f"grad e{epoch}")
+        O.update_last_epoch_stats(epoch)
+        O.update_running_stats(g[f"e{epoch}_in_feats"], g[f"e{epoch}_in_labels"], epoch)
+        for k in BUFFERS:
+            assert_close(getattr(O, k), g[f"e{epoch}_post_{k}"], msg=f"post e{epoch} {k}")
+        assert (O.running_mean_last_epoch is O.running_mean) == bool(g[f"e{epoch}_alias"])    # alias broken in this variant
