@@ -175,6 +175,21 @@ def kernel_rooflines(device):
                     "shape": f"B={b} C={c} U={u} f32", "ms": ms, "algorithmic_bytes": alg,
                     "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
         del x, dy
+    # --- "next" rows: NYUD2 dense map [32,128,114,152] (per-pixel buckets, narrow-row kernels) and STS-B [128,12000]
+    b, c, h, w = 32, 128, 114, 152
+    depth = torch.rand(b * h * w, device=device, generator=g) * 9.3 + 0.7
+    rows = torch.rand(b * h * w, c, device=device, generator=g)
+    bins = ops.bin_scaled(depth, 10.0, 7, 100)
+    t1, sc, t2 = (torch.rand(93, c, device=device, generator=g) + 0.5 for _ in range(3))
+    ms = event_time_ms(lambda: ops.calibrate_fwd_(rows, bins, t1, sc, t2), 10)
+    alg = 2 * rows.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4
+    out.append({"kernel": "dir_fds_calibrate_fwd (narrow rows, NYUD2 dense map)", "bound": "hbm", "shape": f"[{b},{c},{h},{w}] f32, 93 buckets",
+                "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+    ms = event_time_ms(lambda: ops.scatter_stats(rows, bins, 93), 5)
+    alg = rows.numel() * 4 + rows.shape[0] * 4
+    out.append({"kernel": "dir_fds_scatter_stats (narrow rows, NYUD2 dense map)", "bound": "hbm", "shape": f"N={rows.shape[0]} C={c} Nb=93 f32",
+                "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+    del rows
     return out
 
 
