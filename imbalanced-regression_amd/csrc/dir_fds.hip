@@ -75,12 +75,13 @@ extern "C" int dir_fds_bin_index(const float* labels, int n, int bucket_start, i
 // Stage P : every "piece" (<= PIECE_ROWS sorted rows of one bin) x (column tile) is reduced in
 //           float64 registers around the shift K = first row of the bin;
 // Stage C : pieces of a bin are combined in index order -> (count, mean, M2).
-#define GROUP_TILE 1024
+#define GROUP_TILE 256        // rows per grouping wavefront: N / 256 wavefronts keep all 256 CUs busy at N = 191 509
 #define PIECE_ROWS 128
 #define PIECE_UNROLL 8
 
 struct ScatterWs {            // carved from the caller's workspace (all 256-B aligned)
     int32_t* tile_hist;       // [ntiles][nb]   counts, then exclusive prefix over tiles
+    int32_t* totals;          // [nb]           rows per bin
     int32_t* offsets;         // [nb+1]         start of each bin in perm
     int32_t* bin_piece0;      // [nb+1]         first piece of each bin
     int32_t* npieces;         // [1]
@@ -101,6 +102,7 @@ static ScatterWs carve_ws(void* base, int n, int C, int nb) {
     auto take = [&](size_t bytes) { size_t o = off; off = dir_align_up(off + bytes, 256); return o; };
     char* b = static_cast<char*>(base);
     size_t o_hist = take(sizeof(int32_t) * (size_t)w.ntiles * nb);
+    size_t o_tot = take(sizeof(int32_t) * nb);
     size_t o_off = take(sizeof(int32_t) * (nb + 1));
     size_t o_bp = take(sizeof(int32_t) * (nb + 1));
     size_t o_np = take(sizeof(int32_t));
@@ -109,7 +111,7 @@ static ScatterWs carve_ws(void* base, int n, int C, int nb) {
     size_t o_p0 = take(sizeof(int32_t) * (size_t)w.maxpieces);
     size_t o_p1 = take(sizeof(int32_t) * (size_t)w.maxpieces);
     size_t o_part = take(sizeof(double) * (size_t)w.maxpieces * 2 * C);
-    w.tile_hist = (int32_t*)(b + o_hist); w.offsets = (int32_t*)(b + o_off);
+    w.tile_hist = (int32_t*)(b + o_hist); w.totals = (int32_t*)(b + o_tot); w.offsets = (int32_t*)(b + o_off);
     w.bin_piece0 = (int32_t*)(b + o_bp); w.npieces = (int32_t*)(b + o_np);
     w.perm = (int32_t*)(b + o_perm); w.piece_bin = (int32_t*)(b + o_pb);
     w.piece_p0 = (int32_t*)(b + o_p0); w.piece_p1 = (int32_t*)(b + o_p1);
@@ -139,29 +141,47 @@ fds_group_hist_kernel(const int32_t* __restrict__ bins, int n, int nb, int32_t* 
     for (int b = lane; b < nb; b += DIR_WAVE) tile_hist[(size_t)tile * nb + b] = hist[b];
 }
 
-// G2: single workgroup. tile_hist -> exclusive prefix over tiles (per bin); offsets; piece table.
+// G2a: one workgroup per bin: exclusive prefix of that bin's counts over the tiles (parallel scan: wave shuffles +
+// LDS carry), total per bin.
 __global__ void __launch_bounds__(DIR_TPB)
-fds_group_scan_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int maxpieces,
+fds_group_scan_tiles_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int32_t* __restrict__ totals) {
+    __shared__ int32_t wsum[DIR_TPB / DIR_WAVE];
+    __shared__ int32_t carry_sh;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE;
+    if (t == 0) carry_sh = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += DIR_TPB) {
+        const int tile = base + t;
+        const int c = tile < ntiles ? tile_hist[(size_t)tile * nb + b] : 0;
+        int incl = c;                                      // inclusive scan inside the wavefront
+#pragma unroll
+        for (int o = 1; o < DIR_WAVE; o <<= 1) { const int v = __shfl_up(incl, o, DIR_WAVE); if (lane >= o) incl += v; }
+        if (lane == DIR_WAVE - 1) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wid; ++k) woff += wsum[k];
+        const int carry = carry_sh;
+        if (tile < ntiles) tile_hist[(size_t)tile * nb + b] = carry + woff + incl - c;
+        __syncthreads();
+        if (t == DIR_TPB - 1) carry_sh = carry + woff + incl;
+        __syncthreads();
+    }
+    if (t == 0) totals[b] = carry_sh;
+}
+
+// G2b: single workgroup: offsets over bins, piece table.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
                       int32_t* __restrict__ offsets, int32_t* __restrict__ bin_piece0,
                       int32_t* __restrict__ npieces, int32_t* __restrict__ piece_bin,
                       int32_t* __restrict__ piece_p0, int32_t* __restrict__ piece_p1) {
     extern __shared__ __attribute__((aligned(16))) int32_t sh[];     // totals[nb+1], pieces[nb+1]
     int32_t* tot = sh;
     int32_t* pcs = sh + (nb + 1);
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        int run = 0;
-        for (int t = 0; t < ntiles; ++t) {                 // coalesced across b
-            const int c = tile_hist[(size_t)t * nb + b];
-            tile_hist[(size_t)t * nb + b] = run;
-            run += c;
-        }
-        tot[b] = run;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {                                // nb is a few hundred at most
         int o = 0, p = 0;
         for (int b = 0; b < nb; ++b) {
-            const int c = tot[b];
+            const int c = totals[b];
             offsets[b] = o; bin_piece0[b] = p;
             tot[b] = o; pcs[b] = p;
             o += c; p += (c + PIECE_ROWS - 1) / PIECE_ROWS;
@@ -360,8 +380,10 @@ extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t
 
     hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s, bins, n, nb, w.tile_hist);
     DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_group_scan_tiles_kernel, dim3(nb), dim3(DIR_TPB), 0, s, w.tile_hist, w.ntiles, nb, w.totals);
+    DIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(DIR_TPB), 2 * (lds_nb + sizeof(int32_t)), s,
-                       w.tile_hist, w.ntiles, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
+                       w.totals, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
                        w.piece_bin, w.piece_p0, w.piece_p1);
     DIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s,
