@@ -35,6 +35,7 @@ __device__ __forceinline__ uint4 cv_gload(const uint16_t* base, ptrdiff_t elem_o
 struct ConvP {
     const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
     const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
+    const uint16_t* mask;     // optional [M][Cout] bf16: result zeroed where !(mask > 0) (fused ReLU backward)
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int M, KT, cpk, ntn, nblocks;
     int simple;               // 1x1, stride 1, pad 0: row m of the GEMM is row m of x (no index arithmetic at all)
@@ -50,8 +51,11 @@ __device__ __forceinline__ uint32_t cv_f2bf(float f) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int BN>
-__global__ void __launch_bounds__(DIR_TPB)
+// MODE 0: one output tile per workgroup. MODE 1: persistent, the next tile's first K-tile is fetched before the last
+// K-step's MFMAs (32 registers live across the epilogue). MODE 2: persistent, fetched after the
+// accumulators have been converted (no extra register pressure), overlapping only the output stores.
+template <int BN, int MODE>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(3)))
 conv_igemm_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
@@ -63,49 +67,70 @@ conv_igemm_kernel(ConvP p) {
     unsigned char* As = smem;
     unsigned char* Bs = smem + p.nbuf * A_BYTES;
 
-    // ---- workgroup -> (m tile, n tile), XCD-aware and bijective
-    int lin;
-    {
-        const int b = blockIdx.x, q = p.nblocks / 8, r = p.nblocks % 8, xcd = b % 8, i = b / 8;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    // ---- workgroup -> sequence of (m tile, n tile). XCD-aware: the hardware deals workgroup b to XCD b % 8, so the
+    // linear tile space is cut into 8 contiguous chunks (the N-tiles of one M-tile stay on one XCD: the A-tile re-reads
+    // hit that L2) and the workgroups of an XCD stride through their chunk. With gridDim.x == nblocks every workgroup
+    // owns exactly one tile; a smaller (persistent) grid makes each one loop, and the loop prefetches the first K-tile
+    // of the next output tile before the epilogue of the current one, so global-load latency, the bf16 conversion and
+    // the output stores of neighbouring tiles overlap instead of alternating.
+    const int xcd = blockIdx.x % 8;
+    const int cq = p.nblocks / 8, cr = p.nblocks % 8;
+    const int cstart = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int clen = xcd < cr ? cq + 1 : cq;
+    const int gx = ((int)gridDim.x - xcd + 7) / 8;         // workgroups that share this XCD's chunk
+    int tl = blockIdx.x / 8;                               // position inside the chunk
+    if (tl >= clen) return;
+    // Thread coordinates are re-derived from a laundered thread id at the start of every phase (K loop, epilogue) so
+    // that the compiler cannot hoist each phase's LDS / global address registers out of the tile loop, where they
+    // would all be live at once (that costs 80+ VGPRs and a workgroup of occupancy).
+    int t, lane, wave, wm, wn, lrow, lchunk, frow, fhalf;
+    bool odd;
+#define CV_COORDS()                                                                                             \
+    {                                                                                                           \
+        t = threadIdx.x; asm volatile("" : "+v"(t));                                                            \
+        lane = t & 63; wave = t >> 6;                                                                           \
+        wm = (BN == 128) ? (wave >> 1) : wave; wn = (BN == 128) ? (wave & 1) : 0;                               \
+        lrow = t >> 3; lchunk = t & 7; frow = lane & 31; fhalf = lane >> 5; odd = lane & 1;                     \
     }
-    const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
-    const int m0 = mt * CV_BM, n0 = nt * BN;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (BN == 128) ? (wave >> 1) : wave;
-    const int wn = (BN == 128) ? (wave & 1) : 0;
+    CV_COORDS();
 
     // ---- loader coordinates: thread loads the 16-B chunk (t & 7) of rows (t >> 3) + 32 i.
-    // Everything position dependent is computed ONCE: per row a signed element offset of its (hi0, wi0) pixel and a
-    // bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
-    const int lrow = t >> 3, lchunk = t & 7;
+    // Everything position dependent is computed ONCE per output tile: per row a signed element offset of its (hi0, wi0)
+    // pixel and a bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
     int aoff[4];
     uint32_t amask[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        aoff[i] = 0; amask[i] = 0;
-        if (m < p.M) {
-            if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }
-            // (n, ho, wo) from m: float reciprocal + one correction step instead of integer divisions (exact for m < 2^24)
-            int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
-            if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-            int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
-            if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;
-            for (int r = 0; r < p.R; ++r)
-                for (int s2 = 0; s2 < p.S; ++s2)
-                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
-        }
-    }
     const size_t K = (size_t)p.KT * CV_BK;
     const uint16_t* wrow[BROWS];
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0 + lrow + 32 * i) * K + lchunk * 8;
-
     // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch
     int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0;
+#define CV_SETUP(LIN)                                                                                           \
+    {                                                                                                           \
+        const int mt_ = (LIN) / p.ntn, nt_ = (LIN) - mt_ * p.ntn;                                               \
+        const int m0_ = mt_ * CV_BM, n0_ = nt_ * BN;                                                            \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < 4; ++i) {                                                                           \
+            const int m = m0_ + lrow + 32 * i;                                                                  \
+            aoff[i] = 0; amask[i] = 0;                                                                          \
+            if (m < p.M) {                                                                                      \
+                if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }                    \
+                /* (n, ho, wo) from m: float reciprocal + one correction step (exact for m < 2^24) */           \
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;                                        \
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }                    \
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;                                        \
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }                      \
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;                             \
+                aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;                                   \
+                for (int r = 0; r < p.R; ++r)                                                                   \
+                    for (int s2 = 0; s2 < p.S; ++s2)                                                            \
+                        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W)        \
+                            amask[i] |= 1u << (r * p.S + s2);                                                   \
+            }                                                                                                   \
+        }                                                                                                       \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0_ + lrow + 32 * i) * K + lchunk * 8;         \
+        ld_tap = 0; ld_c = 0; ld_r = 0; ld_s = 0;                                                               \
+    }
+
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;              // named registers: no private-memory arrays
     rb2 = rb3 = make_uint4(0, 0, 0, 0);
 
@@ -139,116 +164,146 @@ conv_igemm_kernel(ConvP p) {
         if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, lrow + 64, rb2); CV_ST(Bs, (buf) * B_BYTES, lrow + 96, rb3); } \
     }
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-
-    CV_LOAD_TILE();
-    CV_STORE_TILE(0);
-    __syncthreads();
-    const int frow = lane & 31, fhalf = lane >> 5;
     const bool dbuf = p.nbuf == 2;
-    for (int kt = 0; kt < p.KT; ++kt) {
-        const int buf = dbuf ? (kt & 1) : 0;
-        const bool more = kt + 1 < p.KT;
-        if (more) CV_LOAD_TILE();                              // global loads in flight during the MFMAs
+    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per epilogue staging row
+    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB, over the K-loop buffers)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
+    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
+
+    int lin = cstart + tl;
+    CV_SETUP(lin);
+    CV_LOAD_TILE();
+    for (;;) {
+        const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
+        const int m0 = mt * CV_BM, n0 = nt * BN;
+        const int tl_next = tl + gx;
+        const bool has_next = MODE != 0 && tl_next < clen;
+        f32x16 acc[MI][NI];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[MI], b[NI];
-            const int chunk = kk * 2 + fhalf;
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row = wm * WM + mi * 32 + frow;
-                a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+        if (MODE != 0) CV_COORDS();
+        CV_STORE_TILE(0);
+        __syncthreads();
+        for (int kt = 0; kt < p.KT; ++kt) {
+            const int buf = dbuf ? (kt & 1) : 0;
+            const bool more = kt + 1 < p.KT;
+            if (more) { CV_LOAD_TILE(); }                      // global loads in flight during the MFMAs
+            else if (MODE == 1 && has_next) { CV_SETUP(cstart + tl_next); CV_LOAD_TILE(); }   // ... and during the epilogue
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[MI], b[NI];
+                const int chunk = kk * 2 + fhalf;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = wm * WM + mi * 32 + frow;
+                    a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = wn * 64 + ni * 32 + frow;
+                    b[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
+            if (more) {
+                if (!dbuf) __syncthreads();                  // single stage: everyone is done reading before the overwrite
+                CV_STORE_TILE(dbuf ? (buf ^ 1) : 0);
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
+        // Neighbouring lanes hold neighbouring columns, so lane pairs swap one value per register pair through DPP
+        // (quad_perm [1,0,3,2]) and every lane stores packed bf16x2 dwords: even lanes the even-numbered rows of the
+        // pair, odd lanes the odd ones. Staging rows are padded by 64 B so the two rows of a pair land on disjoint banks.
+        if (MODE != 0) CV_COORDS();
+        float csum[NI], csq[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const uint32_t h0 = cv_f2bf(acc[mi][ni][e]), h1 = cv_f2bf(acc[mi][ni][e + 1]);
+                    const float f0 = __uint_as_float(h0 << 16), f1 = __uint_as_float(h1 << 16);   // statistics of what is stored
+                    csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
+                    const uint32_t send = odd ? h0 : h1;             // what the partner lane needs
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
+                    const uint32_t packed = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
+                    const int row = wm * WM + mi * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * fhalf;
+                    const int col = wn * 64 + ni * 32 + (frow & ~1);
+                    *reinterpret_cast<uint32_t*>(Cs + row * CS_STRIDE + col * 2) = packed;
+                }
+        if (MODE == 2 && has_next) { CV_SETUP(cstart + tl_next); CV_LOAD_TILE(); }   // loads issued before the stores below
+        if (p.stats) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int row = wn * 64 + ni * 32 + frow;
-                b[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
+                csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
+                csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
+                if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
             }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (!dbuf) __syncthreads();                          // single stage: everyone is done reading before the overwrite
-        if (more) CV_STORE_TILE(dbuf ? (buf ^ 1) : 0);
         __syncthreads();
+        if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
+            const int which = t / BN, col = t - which * BN;
+            float s = 0.0f;
+            if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
+            else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
+            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < (CV_BM * CPR) / DIR_TPB; ++i) {
+            const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
+            if (m0 + row < p.M) {
+                uint4 c = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
+                const size_t go = (size_t)(m0 + row) * p.Cout + n0 + ch * 8;
+                if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
+                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const float lo = __uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16);
+                        const float hi = __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u);
+                        cw[q2] = cv_f2bf(lo) | (cv_f2bf(hi) << 16);
+                    }
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+                if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
+                    const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
+                    const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
+                        if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                    }
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+                *reinterpret_cast<uint4*>(p.y + go) = c;
+            }
+        }
+        if (!has_next) break;
+        tl = tl_next;
+        lin = cstart + tl;
+        __syncthreads();                                       // staging reads done before the next tile lands in LDS
     }
+#undef CV_SETUP
+#undef CV_COORDS
 #undef CV_LOAD_TILE
 #undef CV_STORE_TILE
 #undef CV_ST
-
-    // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
-    // Neighbouring lanes hold neighbouring columns, so lane pairs swap one value per register pair through DPP
-    // (quad_perm [1,0,3,2]) and every lane stores packed bf16x2 dwords: even lanes the even-numbered rows of the pair,
-    // odd lanes the odd ones. Staging rows are padded by 64 B so the two rows of a pair land on disjoint banks.
-    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row
-    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB, the K-loop buffers are free now)
-    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
-    float csum[NI], csq[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
-    const bool odd = lane & 1;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const uint32_t h0 = cv_f2bf(acc[mi][ni][e]), h1 = cv_f2bf(acc[mi][ni][e + 1]);
-                const float f0 = __uint_as_float(h0 << 16), f1 = __uint_as_float(h1 << 16);   // statistics of what is stored
-                csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
-                const uint32_t send = odd ? h0 : h1;             // what the partner lane needs
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
-                const uint32_t packed = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
-                const int row = wm * WM + mi * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * fhalf;
-                const int col = wn * 64 + ni * 32 + (frow & ~1);
-                *reinterpret_cast<uint32_t*>(Cs + row * CS_STRIDE + col * 2) = packed;
-            }
-    if (p.stats) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
-            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
-            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
-        }
-    }
-    __syncthreads();
-    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
-        const int which = t / BN, col = t - which * BN;
-        float s = 0.0f;
-        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
-        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
-        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
-    }
-    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
-#pragma unroll
-    for (int i = 0; i < (CV_BM * CPR) / DIR_TPB; ++i) {
-        const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
-        if (m0 + row < p.M) {
-            uint4 c = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
-            const size_t go = (size_t)(m0 + row) * p.Cout + n0 + ch * 8;
-            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
-                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
-                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = __uint_as_float(cw[q] << 16) + __uint_as_float(aw[q] << 16);
-                    const float hi = __uint_as_float(cw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-                    cw[q] = cv_f2bf(lo) | (cv_f2bf(hi) << 16);
-                }
-                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
-            *reinterpret_cast<uint4*>(p.y + go) = c;
-        }
-    }
 }
 
 }  // namespace
@@ -258,18 +313,26 @@ extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
     return (size_t)((M + CV_BM - 1) / CV_BM);
 }
 
+extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
+                                  float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  dir_stream_t stream);
+
 extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
-                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
+                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
+    return dir_conv_fwd_fused(x, w, addend, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+}
 
 extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                             int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
     return dir_conv_fwd_add(x, w, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
 }
 
-extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
-                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
+extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
+                                  float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  dir_stream_t stream) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
     DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
+    DIR_RETURN_IF(relu_mask && (!dir_aligned16(relu_mask) || stats), DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
@@ -281,6 +344,7 @@ extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
     p.stats = stats;
     p.addend = static_cast<const uint16_t*>(addend);
+    p.mask = static_cast<const uint16_t*>(relu_mask);
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
@@ -295,20 +359,28 @@ extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend
     static const int force_nbuf = []() { const char* e = getenv("DIR_CONV_NBUF"); return e ? atoi(e) : 0; }();
     static const int nbuf_kt = []() { const char* e = getenv("DIR_CONV_NBUF_KT"); return e ? atoi(e) : 18; }();
     p.nbuf = force_nbuf ? force_nbuf : (p.KT <= nbuf_kt ? 1 : 2);
-    if (wide) {
-        const int stage = CV_BM * (128 * 2 + 64) + 2048;            // epilogue staging + column partials
-        const int loop = p.nbuf * (CV_BM * CV_ROWB + 128 * CV_ROWB);
-        const int lds = loop > stage ? loop : stage;
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
-        (void)once;
-        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
-    } else {
-        const int stage = CV_BM * (64 * 2 + 64) + 2048;
-        const int loop = p.nbuf * (CV_BM * CV_ROWB + 64 * CV_ROWB);
-        const int lds = loop > stage ? loop : stage;
-        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.nblocks), dim3(DIR_TPB), lds, s, p);
-    }
+    // Grid: DIR_CONV_MODE=0 launches one workgroup per tile; 1 / 2 launch DIR_CONV_PER_CU workgroups per CU that loop
+    // over tiles (see the kernel's MODE).
+    static const int mode = []() { const char* e = getenv("DIR_CONV_MODE"); return e ? atoi(e) : 0; }();
+    static const int per_cu_env = []() { const char* e = getenv("DIR_CONV_PER_CU"); return e ? atoi(e) : 0; }();
+    static const int ncu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int bn = wide ? 128 : 64;
+    const int stage = CV_BM * (bn * 2 + 64) + 2048;                 // epilogue staging + column partials
+    const int loop = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
+    const int lds = loop > stage ? loop : stage;
+    int per_cu = per_cu_env > 0 ? per_cu_env : (160 * 1024) / lds;
+    if (per_cu > 4) per_cu = 4;
+    int grid = p.nblocks;
+    if (mode != 0 && (long long)ncu * per_cu < grid) grid = ncu * per_cu;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
+    (void)once;
+#define CV_LAUNCH(BN_, MODE_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE_>), dim3(grid), dim3(DIR_TPB), lds, s, p)
+    if (wide) { if (mode == 1) CV_LAUNCH(128, 1); else if (mode == 2) CV_LAUNCH(128, 2); else CV_LAUNCH(128, 0); }
+    else      { if (mode == 1) CV_LAUNCH(64, 1);  else if (mode == 2) CV_LAUNCH(64, 2);  else CV_LAUNCH(64, 0); }
+#undef CV_LAUNCH
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -319,20 +391,67 @@ extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend
 // and, optionally, w16_rot [Cin][R][S][Cout] with the taps rotated by 180 degrees (the data-gradient convolution's
 // weight) — instead of a cast + flip + permute + copy chain of library kernels.
 namespace {
-__global__ void __launch_bounds__(DIR_TPB)
-conv_prep_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, uint16_t* __restrict__ w16,
-                         uint16_t* __restrict__ w16_rot) {
-    const size_t n = (size_t)Cout * RS * Cin;
-    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * DIR_TPB) {
-        const uint16_t h = (uint16_t)cv_f2bf(w[i]);
-        w16[i] = h;
+// One layer: w [Cout][RS][Cin] f32 -> w16 (same layout, bf16) and optionally w16_rot [Cin][RS][Cout] with the taps
+// reversed. Cin, Cout % 64 == 0: the (co, ci) transpose of each tap goes through a 64x64 LDS tile, so both the float
+// reads (256 B rows) and the two bf16 writes (128 B rows) are coalesced. Tiles are strided over gridDim.x.
+__device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int Cout, int RS, int Cin,
+                                               uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot) {
+    __shared__ uint16_t tile[64][66];
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;           // 4 rows of 64 per pass
+    if ((Cout & 63) || (Cin & 63)) {                               // generic fallback (not used by ResNet-50's layers)
+        const size_t n = (size_t)Cout * RS * Cin;
+        for (size_t i = (size_t)blockIdx.x * DIR_TPB + t; i < n; i += (size_t)gridDim.x * DIR_TPB) {
+            const uint16_t h = (uint16_t)cv_f2bf(w[i]);
+            w16[i] = h;
+            if (w16_rot) {
+                const int ci = (int)(i % Cin); const size_t t1 = i / Cin; const int tap = (int)(t1 % RS); const int co = (int)(t1 / RS);
+                w16_rot[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = h;
+            }
+        }
+        return;
+    }
+    const int tci = Cin >> 6, tco = Cout >> 6, ntiles = tci * tco * RS;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int ci0 = (tl % tci) << 6; const int t1 = tl / tci; const int tap = t1 % RS; const int co0 = (t1 / RS) << 6;
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) {                         // row = output channel, 64 consecutive input channels
+            const size_t i = ((size_t)(co0 + r) * RS + tap) * Cin + ci0 + tx;
+            const uint16_t h = (uint16_t)cv_f2bf(w[i]);
+            w16[i] = h;
+            tile[r][tx] = h;
+        }
         if (w16_rot) {
-            const int ci = (int)(i % Cin); const size_t t1 = i / Cin; const int tap = (int)(t1 % RS); const int co = (int)(t1 / RS);
-            w16_rot[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = h;
+            __syncthreads();
+#pragma unroll 4
+            for (int r = ty; r < 64; r += 4)                       // row = input channel, 64 consecutive output channels
+                w16_rot[((size_t)(ci0 + r) * RS + (RS - 1 - tap)) * Cout + co0 + tx] = tile[tx][r];
+            __syncthreads();
         }
     }
 }
+
+__global__ void __launch_bounds__(DIR_TPB)
+conv_prep_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, uint16_t* __restrict__ w16,
+                         uint16_t* __restrict__ w16_rot) {
+    conv_prep_body(w, Cout, RS, Cin, w16, w16_rot);
+}
+
+// blockIdx.y = layer; the layer's row of the table holds its pointers and extents
+__global__ void __launch_bounds__(DIR_TPB)
+conv_prep_weights_batched_kernel(const long long* __restrict__ table) {
+    const long long* e = table + (size_t)blockIdx.y * 6;
+    conv_prep_body(reinterpret_cast<const float*>(e[0]), (int)e[3], (int)e[4], (int)e[5],
+                   reinterpret_cast<uint16_t*>(e[1]), reinterpret_cast<uint16_t*>(e[2]));
+}
 }  // namespace
+
+extern "C" int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t stream) {
+    DIR_RETURN_IF(!table || nlayers <= 0 || nlayers > 65535, DIR_EINVAL);
+    hipLaunchKernelGGL(conv_prep_weights_batched_kernel, dim3(128, nlayers), dim3(DIR_TPB), 0, dir_s(stream),
+                       static_cast<const long long*>(table));
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
 
 extern "C" int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
                                      dir_stream_t stream) {

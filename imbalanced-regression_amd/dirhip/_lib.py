@@ -49,8 +49,11 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
     "dir_conv_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dir_conv_prep_weights_batched": (c_int, [c_void_p, c_int, c_void_p]),
     "dir_conv_fwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_void_p]),
+    "dir_conv_fwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_void_p]),
     "dir_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_void_p]),
     "dir_conv_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -27,7 +27,8 @@ def _ws(dtype_code, m, c, device):
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training, partial):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training, partial,
+                deferred=None):
         if not x.is_cuda:
             raise L.DirHipError(f"bn_act: input on {x.device}; the fused BatchNorm runs only as HIP kernels (no CPU fallback)")
         x = _nhwc(x)
@@ -60,6 +61,7 @@ class _BNActFn(torch.autograd.Function):
             ctx.save_for_backward(x, gamma, beta, y if (relu and residual is not None) else None, mean, rstd)
             ctx.relu = bool(relu)
             ctx.has_res = residual is not None
+            ctx.deferred = deferred
         else:
             L.check(L.lib().dir_bn_fwd_eval(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
                                             L.ptr(running_mean), L.ptr(running_var), float(eps), int(relu), L.ptr(ws),
@@ -79,19 +81,31 @@ class _BNActFn(torch.autograd.Function):
         m = n * h * w
         code = _DT[x.dtype]
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        relu = ctx.relu
+        if ctx.deferred is not None and ctx.deferred[0]:
+            # the consumer's data-gradient kernel already applied this node's ReLU backward (conv._ConvFn, relu_input):
+            # dout IS the masked gradient, which is also the shortcut's gradient as it stands
+            relu, y = False, None
+            dres = None
+        else:
+            dres = torch.empty_like(x) if ctx.has_res else None
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         ws = _ws(code, m, c, x.device)
         L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
-                                   L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(ctx.relu),
+                                   L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(relu),
                                    L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        if dres is None and ctx.has_res:
+            dres = dout
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, relu=True, residual=None, partial=None):
+def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False):
     """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``. ``partial`` =
-    the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only)."""
+    the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only).
+    ``defer_relu_grad``: the result carries a flag (``._dir_relu_flag``) that the ONE consumer of the result may claim
+    (``conv.conv_bn_input(..., relu_flag=)``), promising to deliver the gradient with this node's ReLU backward already
+    applied; the backward here then skips the mask (and the read of the saved output, and the shortcut-gradient write)."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         counter = getattr(bn, "_dir_step_counter", None)
@@ -103,8 +117,12 @@ def bn_act(x, bn, relu=True, residual=None, partial=None):
         raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not implemented")
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
-                          partial if training else None)
+    deferred = [False] if (defer_relu_grad and relu and training and torch.is_grad_enabled()) else None
+    y = _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
+                       partial if training else None, deferred)
+    if deferred is not None:
+        y._dir_relu_flag = deferred
+    return y
 
 
 class BatchCounters:

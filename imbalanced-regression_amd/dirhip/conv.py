@@ -13,7 +13,7 @@ def supported(cin, cout):
     return cin % 64 == 0 and cout % 64 == 0
 
 
-def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None):
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None):
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -35,8 +35,12 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None):
         assert addend.shape == y.shape and addend.dtype == torch.bfloat16 and not want_stats
         if not addend.is_contiguous(memory_format=torch.channels_last):
             addend = addend.contiguous(memory_format=torch.channels_last)
-    L.check(L.lib().dir_conv_fwd_add(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(y), L.ptr(stats), n, h, wd, cin, cout, r, s,
-                                     stride, padding, L.stream_ptr(x.device)), "dir_conv_fwd")
+    if relu_mask is not None:
+        assert relu_mask.shape == y.shape and relu_mask.dtype == torch.bfloat16 and not want_stats
+        if not relu_mask.is_contiguous(memory_format=torch.channels_last):
+            relu_mask = relu_mask.contiguous(memory_format=torch.channels_last)
+    L.check(L.lib().dir_conv_fwd_fused(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(relu_mask), L.ptr(y), L.ptr(stats), n, h, wd,
+                                       cin, cout, r, s, stride, padding, L.stream_ptr(x.device)), "dir_conv_fwd")
     return (y, stats) if want_stats else y
 
 
@@ -66,9 +70,15 @@ class _ConvFn(torch.autograd.Function):
     kernel ``dir_conv_wgrad``. Only the data gradient of the six stride-2 layers still uses the library kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input):
+    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input):
         ctx.stride, ctx.padding = stride, padding
         ctx.alias_input = alias_input
+        # relu_input: x is the output of a relu(bn(.) + shortcut) node that was promised its gradient with the ReLU
+        # backward already applied (bn.bn_act(defer_relu_grad=True)): the data gradient is masked with x > 0 on store
+        ctx.relu_input = relu_input
+        # the statistics output never carries a gradient: without this autograd would zero-fill a [rows][2][Cout]
+        # float tensor for it on every backward (one fill kernel per layer and step)
+        ctx.set_materialize_grads(False)
         if want_stats:
             y, stats = conv2d_igemm(x, w16, stride, padding, want_stats=True)
             ctx.mark_non_differentiable(stats)
@@ -84,6 +94,9 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstats, dalias=None):
         x, w16, w16_rot = ctx.saved_tensors
+        if dy is None:                                                           # only the alias output was used
+            assert not ctx.relu_input
+            return dalias, None, None, None, None, None, None, None, None
         if dalias is not None and dalias.dtype != torch.bfloat16:
             dalias = dalias.to(torch.bfloat16)
         if dy.dtype != torch.bfloat16:
@@ -94,7 +107,8 @@ class _ConvFn(torch.autograd.Function):
         if need_dx and w16_rot is not None:
             # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
             # in/out-transposed weights and padding R-1-pad
-            dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias)
+            dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias,
+                              relu_mask=x if ctx.relu_input else None)
             dalias = None
             need_dx = False
         dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
@@ -104,7 +118,7 @@ class _ConvFn(torch.autograd.Function):
                 [True, False, False])[0]
         if dalias is not None:                                                   # strided layer: eager accumulation
             dx = dalias if dx is None else dx + dalias
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -121,33 +135,106 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_hook(invalidate_weight_cache)
 
 
-def conv_bn_input(x, conv, want_stats, alias_input=False):
+class _PreparedWeights:
+    """bf16 operands of one conv layer (persistent buffers) + the key of the master weight they were made from."""
+    __slots__ = ("key", "w16", "w16_rot", "conv_ref", "shape")
+
+    def __init__(self, conv):
+        import weakref
+        w = conv.weight
+        cout, cin, r, s = w.shape
+        self.shape = (cout, r * s, cin)
+        self.w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
+        self.w16_rot = None
+        if conv.stride[0] == 1 and supported(cout, cin):
+            # [Cin][R][S][Cout], taps rotated by 180 degrees: the weight of the data-gradient convolution
+            self.w16_rot = torch.empty((cin, cout, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
+        self.key = None
+        self.conv_ref = weakref.ref(conv)
+
+
+def _weight_key(w):
+    return (_GENERATION[0], w._version, w.data_ptr())
+
+
+_REGISTRY = {}      # device -> list of _PreparedWeights (every conv layer that went through conv_bn_input there)
+_TABLES = {}        # device -> (tuple of master-weight pointers, device table [n][6] int64, list of entries)
+
+
+def _refresh_all(device):
+    """Re-make the bf16 operands of every registered layer on ``device`` in ONE launch (after an optimizer step all of
+    them are stale at once). Layers whose module died, moved or is not a dense channels_last float32 weight are skipped
+    here and fall back to the single-layer path."""
+    entries = [st for st in _REGISTRY.get(device, []) if st.conv_ref() is not None]
+    _REGISTRY[device] = entries
+    live = []
+    for st in entries:
+        conv = st.conv_ref()
+        w = conv.weight
+        if w.device == device and w.dtype == torch.float32 and w.is_contiguous(memory_format=torch.channels_last) \
+                and tuple(w.shape) == (st.shape[0], st.shape[2]) + tuple(conv.kernel_size):
+            live.append((st, w))
+    if not live:
+        return
+    ptrs = tuple(w.data_ptr() for _, w in live)
+    cached = _TABLES.get(device)
+    if cached is None or cached[0] != ptrs:
+        rows = [[w.data_ptr(), st.w16.data_ptr(), 0 if st.w16_rot is None else st.w16_rot.data_ptr(),
+                 st.shape[0], st.shape[1], st.shape[2]] for st, w in live]
+        cached = (ptrs, torch.tensor(rows, dtype=torch.int64).to(device))
+        _TABLES[device] = cached
+    L.check(L.lib().dir_conv_prep_weights_batched(L.ptr(cached[1]), len(live), L.stream_ptr(device)),
+            "dir_conv_prep_weights_batched")
+    for st, w in live:
+        st.key = _weight_key(w)
+
+
+def _prepared(conv):
+    """bf16 operands of ``conv.weight``, valid for the current optimizer generation."""
+    w = conv.weight
+    st = getattr(conv, "_dir_w16", None)
+    if st is None or st.w16.device != w.device:
+        st = _PreparedWeights(conv)
+        object.__setattr__(conv, "_dir_w16", st)
+        _REGISTRY.setdefault(w.device, []).append(st)
+    key = _weight_key(w)
+    if st.key != key and st.key is not None:
+        _refresh_all(w.device)                     # everything went stale together: one launch for the whole network
+    if st.key != key:                              # first use, or a layer the batched path skipped
+        wd = w.detach()
+        if wd.dtype != torch.float32:
+            wd = wd.float()
+        if not wd.is_contiguous(memory_format=torch.channels_last):
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        cout, rs, cin = st.shape
+        r = conv.kernel_size[0]
+        L.check(L.lib().dir_conv_prep_weights(L.ptr(wd), cout, r, rs // r, cin, L.ptr(st.w16), L.ptr(st.w16_rot),
+                                              L.stream_ptr(wd.device)), "dir_conv_prep_weights")
+        st.key = key
+    return st.w16, st.w16_rot
+
+
+def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     """Apply ``conv`` (an ``nn.Conv2d`` with bias=False, Cin/Cout multiples of 64) to a bf16 channels_last tensor with
     the MFMA kernel. Returns ``(y, partial_stats or None)``. The bf16 copy of the fp32 master weight is cached until
     the next optimizer step / in-place edit (one cast per step instead of one per use: train forward, epoch-tail
-    forward and the backward share it)."""
+    forward and the backward share it), and all layers of a network are re-cast by one launch. The operands live in
+    persistent buffers that are rewritten in place: a backward pass must run before the optimizer step that follows
+    its forward pass (as in any training loop)."""
     w = conv.weight
-    key = (_GENERATION[0], w._version, w.data_ptr())
-    cache = getattr(conv, "_dir_w16", None)
-    if cache is None or cache[0] != key:
-        wd = w.detach()
-        if not wd.is_contiguous(memory_format=torch.channels_last):
-            wd = wd.contiguous(memory_format=torch.channels_last)
-        cout, cin, r, s = wd.shape
-        w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=wd.device, memory_format=torch.channels_last)
-        w16_rot = None
-        if conv.stride[0] == 1 and supported(cout, cin):
-            # [Cin][R][S][Cout], taps rotated by 180 degrees: the weight of the data-gradient convolution
-            w16_rot = torch.empty((cin, cout, r, s), dtype=torch.bfloat16, device=wd.device, memory_format=torch.channels_last)
-        L.check(L.lib().dir_conv_prep_weights(L.ptr(wd), cout, r, s, cin, L.ptr(w16), L.ptr(w16_rot),
-                                              L.stream_ptr(wd.device)), "dir_conv_prep_weights")
-        conv._dir_w16 = (key, w16, w16_rot)
-    else:
-        w16, w16_rot = cache[1], cache[2]
+    w16, w16_rot = _prepared(conv)
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
-    y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if torch.is_grad_enabled() else None, conv.stride[0],
-                                    conv.padding[0], want_stats, alias_input and torch.is_grad_enabled() and x.requires_grad)
+        relu_flag = None
+    grad_mode = torch.is_grad_enabled()
+    aliasing = bool(alias_input and grad_mode and x.requires_grad)
+    # relu_flag (a one-element list made by bn_act(defer_relu_grad=True) for the tensor x): claimed only when EVERY use
+    # of x goes through this node (alias mode) and the data gradient is our own kernel, which can mask on store
+    relu_input = bool(relu_flag is not None and aliasing and w16_rot is not None and not relu_flag[0])
+    if relu_input:
+        relu_flag[0] = True
+    y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if grad_mode else None, conv.stride[0], conv.padding[0],
+                                    want_stats, aliasing, relu_input)
     if alias_input:
         return y, stats, (alias if alias is not None else x)
     return y, stats

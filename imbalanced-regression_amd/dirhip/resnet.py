@@ -6,13 +6,16 @@ reference checkpoints load), same initialisation stream, same forward contract
 (``(pred, encoding)`` when training with FDS, else ``pred``; the returned ``encoding`` is the tensor
 ``FDS.smooth`` calibrated in place — SURVEY A.2).
 
-Backbone: convolutions are bf16 MFMA implicit-GEMM library kernels (MIOpen, channels_last, driven by
-``dirhip.parallel.DataParallelEngine``'s autocast); every BatchNorm (+ residual add) (+ ReLU) is ONE fused
-hand-written HIP node (``dirhip.bn.bn_act`` -> ``dir_bn_*``); the pool -> FDS calibrate -> linear -> weighted-loss
-tail is the hand-written HIP path and always fp32. GPU only (no CPU fallback).
+Backbone (bf16, channels_last, under ``dirhip.parallel.DataParallelEngine``'s autocast): every convolution with
+Cin, Cout % 64 == 0 is the hand-written MFMA implicit GEMM (``dirhip.conv`` -> ``dir_conv_*``: forward, stride-1 data
+gradient, weight gradient; BatchNorm statistics in its epilogue); the 7x7 stem and the six stride-2 data gradients use
+the library. Every BatchNorm (+ residual add) (+ ReLU) is ONE fused hand-written HIP node (``dirhip.bn.bn_act`` ->
+``dir_bn_*``); the pool -> FDS calibrate -> linear -> weighted-loss tail is the hand-written HIP path and always fp32.
+GPU only (no CPU fallback).
 """
 import logging
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -24,14 +27,18 @@ from .pool import maxpool3x3s2
 
 print = logging.info
 
+# A/B switches for measurements (comma separated): "proj_alias" = eager gradient add at projection-shortcut blocks,
+# "relu_defer" = ReLU backward inside the BatchNorm node instead of the next block's data-gradient kernel
+_DISABLED = set(filter(None, os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")))
 
-def _conv_bn(x, conv, bn, relu, residual=None):
+
+def _conv_bn(x, conv, bn, relu, residual=None, defer_relu_grad=False):
     """conv -> BatchNorm (+ residual) (+ ReLU). bf16 activations: hand-written MFMA implicit-GEMM convolution whose
     epilogue already produced the BatchNorm statistics, then ONE fused normalise/add/ReLU pass. fp32 activations
     (parity mode): library convolution + the fused HIP BatchNorm node."""
     if x.dtype == torch.bfloat16 and _igemm_ok(conv.in_channels, conv.out_channels):
         y, partial = conv_bn_input(x, conv, want_stats=bn.training)
-        return bn_act(y, bn, relu=relu, residual=residual, partial=partial)
+        return bn_act(y, bn, relu=relu, residual=residual, partial=partial, defer_relu_grad=defer_relu_grad)
     return bn_act(conv(x), bn, relu=relu, residual=residual)
 
 
@@ -53,16 +60,22 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if self.downsample is None and x.dtype == torch.bfloat16 and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels):
-            # identity shortcut: conv1's node also hands back the block input, so the two gradients that meet at the
-            # block input are summed inside conv1's data-gradient kernel instead of by an eager add
-            y, partial, shortcut = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True)
+        if x.dtype == torch.bfloat16 and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels) and \
+                (self.downsample is None or "proj_alias" not in _DISABLED):
+            # conv1's node also hands back the block input, and the shortcut branch (identity or projection) reads THAT:
+            # the two gradients that meet at the block input are then summed inside conv1's data-gradient kernel
+            # (its `addend`) instead of by an eager add kernel
+            # (and, when x is the previous block's relu(bn3 + shortcut), that node's ReLU backward is applied there too)
+            y, partial, xin = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True,
+                                            relu_flag=getattr(x, "_dir_relu_flag", None))
             y = bn_act(y, self.bn1, relu=True, partial=partial)
+            shortcut = xin if self.downsample is None else _conv_bn(xin, self.downsample[0], self.downsample[1], relu=False)
         else:
             shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
             y = _conv_bn(x, self.conv1, self.bn1, relu=True)
         y = _conv_bn(y, self.conv2, self.bn2, relu=True)
-        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut)    # relu(bn3(conv3(.)) + shortcut)
+        # relu(bn3(conv3(.)) + shortcut); the next block's conv1 may take over the ReLU backward of this node
+        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut, defer_relu_grad="relu_defer" not in _DISABLED)
 
 
 class ResNet(nn.Module):

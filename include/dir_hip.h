@@ -234,6 +234,9 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
                           dir_stream_t stream);
+/* The same for all layers of a network in ONE launch (52 launches per optimizer step otherwise).  table: device
+ * array [nlayers][6] of int64: { w (const float*), w16, w16_rot (0 = none), Cout, R*S, Cin }. */
+int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t stream);
 int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 /* y = bf16(bf16(conv(x, w)) + addend): the gradient accumulation autograd would run as a separate add kernel at a
@@ -241,6 +244,14 @@ int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int
  * loop.  addend [N, Ho, Wo, Cout] bf16; stats must be NULL. */
 int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
                      int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
+/* ... and additionally zeroed where !(relu_mask > 0): y = relu'(relu_mask) * bf16(bf16(conv(x, w)) + addend).  With x = dY
+ * of a block's first convolution, addend = the shortcut gradient and relu_mask = the block input (the output of the
+ * previous block's relu(bn3(.) + shortcut), resnet.py:66-68), y is the gradient that BatchNorm node needs with its ReLU
+ * backward already applied, so dir_bn_bwd runs with relu = 0 and re-reads neither its saved output nor writes a
+ * separate shortcut gradient.  addend, relu_mask: [N, Ho, Wo, Cout] bf16, either may be NULL; stats must be NULL when
+ * one of them is given. */
+int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y, float* stats,
+                       int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the

@@ -156,3 +156,112 @@ def test_bottleneck_fused_shortcut_gradient_matches_unfused():
     assert_close(gx1.cpu().numpy(), gx2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
     for a, b in zip(gp1, gp2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_projection_bottleneck_fused_shortcut_gradient_matches_unfused(stride):
+    """Projection-shortcut bottleneck (first block of a stage): the block input feeds conv1 and the downsample conv; the
+    sum of their data gradients, fused into conv1's data-gradient kernel, must match autograd's eager add."""
+    import torch.nn as nn
+    from dirhip import resnet as R
+    torch.manual_seed(1)
+    down = nn.Sequential(nn.Conv2d(128, 256, 1, stride=stride, bias=False), nn.BatchNorm2d(256))
+    blk = R.Bottleneck(128, 64, stride=stride, downsample=down).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    ho = 16 // stride
+    x0 = torch.randn(8, 128, 16, 16, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, 256, ho, ho, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        for p in blk.parameters():
+            p.grad = None
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        xin = x * 1.0
+        if fused:
+            out = blk(xin)
+        else:
+            sc = R._conv_bn(xin, blk.downsample[0], blk.downsample[1], relu=False)
+            y = R._conv_bn(xin, blk.conv1, blk.bn1, relu=True)
+            y = R._conv_bn(y, blk.conv2, blk.bn2, relu=True)
+            out = R._conv_bn(y, blk.conv3, blk.bn3, relu=True, residual=sc)
+        out.backward(dy)
+        return out.detach().float(), x.grad.float(), [p.grad.clone() for p in blk.parameters()]
+
+    o1, gx1, gp1 = run(True)
+    o2, gx2, gp2 = run(False)
+    assert torch.equal(o1, o2)
+    assert_close(gx1.cpu().numpy(), gx2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
+    for a, b in zip(gp1, gp2):
+        assert torch.equal(a, b)
+
+
+def test_batched_weight_preparation_matches_single_layer_path():
+    """One launch re-casts every registered layer after an optimizer step; operands must equal the per-layer kernel's."""
+    import torch.nn as nn
+    from dirhip import conv as C
+    torch.manual_seed(2)
+    convs = [nn.Conv2d(64, 128, 1, bias=False), nn.Conv2d(128, 128, 3, padding=1, bias=False),
+             nn.Conv2d(128, 64, 3, stride=2, padding=1, bias=False)]
+    convs = [c.cuda().to(memory_format=torch.channels_last) for c in convs]
+    opt = torch.optim.SGD([p for c in convs for p in c.parameters()], lr=0.5)
+    x = torch.randn(2, 64, 8, 8, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def fwd():
+        y, _ = C.conv_bn_input(x, convs[0], False)
+        y, _ = C.conv_bn_input(y, convs[1], False)
+        y, _ = C.conv_bn_input(y, convs[2], False)
+        return y
+
+    fwd().float().square().mean().backward()
+    before = [c._dir_w16.w16.clone() for c in convs]
+    opt.step()                                                     # every layer stale at once -> batched refresh
+    fwd()
+    for c, old in zip(convs, before):
+        st = c._dir_w16
+        w = c.weight.detach()
+        assert not torch.equal(st.w16, old)
+        assert torch.equal(st.w16, w.to(torch.bfloat16))
+        if st.w16_rot is not None:
+            ref_rot = w.to(torch.bfloat16).flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+            assert torch.equal(st.w16_rot, ref_rot)
+        else:
+            assert c.stride[0] == 2
+
+
+def test_deferred_relu_backward_is_bit_identical():
+    """relu(bn3 + shortcut) -> next block: the next conv1's data-gradient kernel applies that ReLU's backward on store
+    (dir_conv_fwd_fused) and the BatchNorm backward skips its mask. Must be bit-identical to the unfused order."""
+    from dirhip import resnet as R
+    torch.manual_seed(3)
+    blk1 = R.Bottleneck(256, 64).cuda().to(memory_format=torch.channels_last)
+    blk2 = R.Bottleneck(256, 64).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x0 = torch.randn(8, 256, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, 256, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    params = list(blk1.parameters()) + list(blk2.parameters())
+
+    def run(defer):
+        for p in params:
+            p.grad = None
+        for m in list(blk1.modules()) + list(blk2.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        x = x0.clone().requires_grad_(True)
+        mid = blk1(x * 1.0)
+        flag = mid._dir_relu_flag
+        if not defer:
+            del mid._dir_relu_flag
+        out = blk2(mid)
+        assert flag[0] == defer
+        out.backward(dy)
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]
+
+    o1, gx1, gp1 = run(True)
+    o2, gx2, gp2 = run(False)
+    assert torch.equal(o1, o2)
+    assert torch.equal(gx1, gx2)
+    for a, b in zip(gp1, gp2):
+        assert torch.equal(a, b)
