@@ -62,7 +62,12 @@ template <> struct Vec<bf16_t> {
     static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = f2bf(o[2 * i]) | (f2bf(o[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) {                               // one v_cvt_pk_bf16_f32 (RNE, quiet NaN) per pair on gfx950
+            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const f32x2_t v = {o[2 * i], o[2 * i + 1]};
+            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+        }
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -130,8 +135,8 @@ bn_stats_partial_kernel(const T* __restrict__ x, int64_t M, int C, BnGeom g, flo
 // row-block axis, float64, fixed-order LDS combine. FC = 8 for short partial lists; FC = 2 (128 slices) when the
 // conv epilogue produced thousands of rows (one per 128-row tile) — the loop is a chain of L2 round trips, so its
 // length, not the bytes, is what costs. Returns the two sums for channel blockIdx.x*FC + t in threads t < FC.
-template <int FC>
-__device__ __forceinline__ bool column_sums(const float* __restrict__ partial, int rblocks, int C, double& s0, double& s1) {
+template <int FC, typename PT>
+__device__ __forceinline__ bool column_sums(const PT* __restrict__ partial, int rblocks, int C, double& s0, double& s1) {
     constexpr int SL = DIR_TPB / FC;
     __shared__ double sh[2][DIR_TPB];
     const int t = threadIdx.x, ch = t % FC, sl = t / FC;
@@ -154,15 +159,42 @@ __device__ __forceinline__ bool column_sums(const float* __restrict__ partial, i
 }
 
 // coef layout in the workspace: [0][C] = a (scale), [1][C] = b (shift)
+// Long partial lists (the convolution epilogue writes one row per 128 output pixels: 6272 rows for 256 x 56 x 56)
+// are first folded to <= 32 rows of doubles by many workgroups; a lone C/8-workgroup pass over them is latency bound.
 template <int FC>
 __global__ void __launch_bounds__(DIR_TPB)
-bn_finalize_train_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
+bn_fold_partials_kernel(const float* __restrict__ partial, int rows, int C, int rows_per_split, double* __restrict__ folded) {
+    constexpr int SL = DIR_TPB / FC;
+    __shared__ double sh[2][DIR_TPB];
+    const int t = threadIdx.x, ch = t % FC, sl = t / FC;
+    const int c = blockIdx.x * FC + ch;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = r0 + sl; r < r1; r += SL) {
+            a += (double)partial[((size_t)r * 2 + 0) * C + c];
+            b += (double)partial[((size_t)r * 2 + 1) * C + c];
+        }
+    }
+    sh[0][t] = a; sh[1][t] = b;
+    __syncthreads();
+    if (t >= FC || c >= C) return;
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < SL; ++k) { a += sh[0][k * FC + t]; b += sh[1][k * FC + t]; }
+    folded[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
+    folded[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
+}
+
+template <int FC, typename PT>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_finalize_train_kernel(const PT* __restrict__ partial, int rblocks, int64_t M, int C,
                          const float* __restrict__ gamma, const float* __restrict__ beta,
                          float* __restrict__ running_mean, float* __restrict__ running_var,
                          double momentum, double eps, float* __restrict__ save_mean, float* __restrict__ save_rstd,
                          float* __restrict__ coef) {
     double s, q;
-    if (!column_sums<FC>(partial, rblocks, C, s, q)) return;
+    if (!column_sums<FC, PT>(partial, rblocks, C, s, q)) return;
     const int c = blockIdx.x * FC + threadIdx.x;
     const double n = (double)M;
     const double mean = s / n;
@@ -311,7 +343,7 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int rblocks, int64_t M
                        const float* __restrict__ save_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                        float* __restrict__ coef) {
     double sg, sgx;
-    if (!column_sums<FC>(partial, rblocks, C, sg, sgx)) return;
+    if (!column_sums<FC, float>(partial, rblocks, C, sg, sgx)) return;
     const int c = blockIdx.x * FC + threadIdx.x;
     const double mean = (double)save_mean[c], rstd = (double)save_rstd[c], n = (double)M;
     const double dg = rstd * (sgx - mean * sg);
@@ -420,8 +452,21 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
         }
         // (a 2-channel x 128-slice variant for the conv epilogue's long partial lists measured slower — 16.6 vs 11.5 us:
         //  its 8-byte loads touch 32 cache lines per wave instruction)
-        hipLaunchKernelGGL(bn_finalize_train_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C, gamma, beta,
-                               running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+        int splits = prow / 64;                                        // >= 64 rows per fold workgroup
+        if (splits > 32) splits = 32;
+        if (splits > g.rblocks / 2) splits = g.rblocks / 2;            // folded doubles live in the (unused) partial area
+        if (ext_partial && splits >= 4) {
+            const int rps = dir_cdiv(prow, splits);
+            splits = dir_cdiv(prow, rps);
+            double* folded = reinterpret_cast<double*>(w.partial);
+            hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3(dir_cdiv(C, 8), splits), dim3(DIR_TPB), 0, s, part, prow, C, rps, folded);
+            DIR_LAUNCH_CHECK();
+            hipLaunchKernelGGL((bn_finalize_train_kernel<8, double>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, folded, splits, M, C,
+                               gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+        } else {
+            hipLaunchKernelGGL((bn_finalize_train_kernel<8, float>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C,
+                               gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
+        }
     } else {
         hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
     }

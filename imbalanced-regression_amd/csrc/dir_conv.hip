@@ -51,11 +51,44 @@ __device__ __forceinline__ uint32_t cv_f2bf(float f) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// MODE 0: one output tile per workgroup. MODE 1: persistent, the next tile's first K-tile is fetched before the last
-// K-step's MFMAs (32 registers live across the epilogue). MODE 2: persistent, fetched after the
-// accumulators have been converted (no extra register pressure), overlapping only the output stores.
-template <int BN, int MODE>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(3)))
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two floats -> packed bf16x2 (round to nearest even, quiet NaN): one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t cv_pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// Accumulators -> bf16 -> LDS staging tile [128][CS_STRIDE]. C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): registers e, e+1 of a lane are vertically adjacent elements, so one
+// v_cvt_pk_bf16_f32 converts both and the two halves go out as ds_write_b16 / ds_write_b16_d16_hi to rows r, r+1 -
+// 1.5 instructions per element and no cross-lane traffic (a software round + DPP pair exchange cost ~10).
+// STATS: per-lane sums of the ROUNDED values and their squares (what the following BatchNorm will read).
+template <int MI, int NI, int CS_STRIDE, bool STATS>
+__device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsigned char* cbase, float (&csum)[NI], float (&csq)[NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const uint32_t pk = cv_pack_bf16(acc[mi][ni][e], acc[mi][ni][e + 1]);
+                unsigned char* d = cbase + (mi * 32 + (e & 3) + 8 * (e >> 2)) * CS_STRIDE + ni * 64;
+                *reinterpret_cast<uint16_t*>(d) = (uint16_t)pk;
+                *reinterpret_cast<uint16_t*>(d + CS_STRIDE) = (uint16_t)(pk >> 16);
+                if (STATS) {
+                    const float f0 = __uint_as_float(pk << 16), f1 = __uint_as_float(pk & 0xffff0000u);
+                    csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
+                }
+            }
+}
+
+// PF = prefetch distance of the global loads in K-steps. The K loop is bound by load latency, not by MFMA or LDS
+// throughput: a 32 KB K-tile takes > 1 us to arrive under load while its 16 MFMAs per wavefront take 0.2 us, so the
+// rate is (bytes in flight per CU) / latency. PF = 2 keeps two K-tiles per workgroup in flight in two register sets
+// (p, q) for 32 more VGPRs (2 instead of 3 wavefronts per SIMD, which the 64 KB two-stage LDS image allows anyway).
+template <int BN, int PF>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(PF == 1 ? 3 : 2)))
 conv_igemm_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
@@ -67,243 +100,231 @@ conv_igemm_kernel(ConvP p) {
     unsigned char* As = smem;
     unsigned char* Bs = smem + p.nbuf * A_BYTES;
 
-    // ---- workgroup -> sequence of (m tile, n tile). XCD-aware: the hardware deals workgroup b to XCD b % 8, so the
-    // linear tile space is cut into 8 contiguous chunks (the N-tiles of one M-tile stay on one XCD: the A-tile re-reads
-    // hit that L2) and the workgroups of an XCD stride through their chunk. With gridDim.x == nblocks every workgroup
-    // owns exactly one tile; a smaller (persistent) grid makes each one loop, and the loop prefetches the first K-tile
-    // of the next output tile before the epilogue of the current one, so global-load latency, the bf16 conversion and
-    // the output stores of neighbouring tiles overlap instead of alternating.
-    const int xcd = blockIdx.x % 8;
-    const int cq = p.nblocks / 8, cr = p.nblocks % 8;
-    const int cstart = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-    const int clen = xcd < cr ? cq + 1 : cq;
-    const int gx = ((int)gridDim.x - xcd + 7) / 8;         // workgroups that share this XCD's chunk
-    int tl = blockIdx.x / 8;                               // position inside the chunk
-    if (tl >= clen) return;
-    // Thread coordinates are re-derived from a laundered thread id at the start of every phase (K loop, epilogue) so
-    // that the compiler cannot hoist each phase's LDS / global address registers out of the tile loop, where they
-    // would all be live at once (that costs 80+ VGPRs and a workgroup of occupancy).
-    int t, lane, wave, wm, wn, lrow, lchunk, frow, fhalf;
-    bool odd;
-#define CV_COORDS()                                                                                             \
-    {                                                                                                           \
-        t = threadIdx.x; asm volatile("" : "+v"(t));                                                            \
-        lane = t & 63; wave = t >> 6;                                                                           \
-        wm = (BN == 128) ? (wave >> 1) : wave; wn = (BN == 128) ? (wave & 1) : 0;                               \
-        lrow = t >> 3; lchunk = t & 7; frow = lane & 31; fhalf = lane >> 5; odd = lane & 1;                     \
+    // ---- workgroup -> (m tile, n tile), XCD-aware and bijective: the hardware deals workgroup b to XCD b % 8, so the
+    // linear tile space is cut into 8 contiguous chunks and the N-tiles of one M-tile run on the same XCD (the A-tile
+    // re-reads hit that L2)
+    int lin;
+    {
+        const int b = blockIdx.x, q = p.nblocks / 8, r = p.nblocks % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
-    CV_COORDS();
+    const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
+    const int m0 = mt * CV_BM, n0 = nt * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
 
     // ---- loader coordinates: thread loads the 16-B chunk (t & 7) of rows (t >> 3) + 32 i.
-    // Everything position dependent is computed ONCE per output tile: per row a signed element offset of its (hi0, wi0)
-    // pixel and a bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
+    // Everything position dependent is computed ONCE: per row a signed element offset of its (hi0, wi0) pixel and a
+    // bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
+    const int lrow = t >> 3, lchunk = t & 7;
     int aoff[4];
     uint32_t amask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        aoff[i] = 0; amask[i] = 0;
+        if (m < p.M) {
+            if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }
+            // (n, ho, wo) from m: float reciprocal + one correction step instead of integer divisions (exact for m < 2^24)
+            int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+            if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+            int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+            if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
+        }
+    }
     const size_t K = (size_t)p.KT * CV_BK;
     const uint16_t* wrow[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0 + lrow + 32 * i) * K + lchunk * 8;
+
     // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch
     int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0;
-#define CV_SETUP(LIN)                                                                                           \
-    {                                                                                                           \
-        const int mt_ = (LIN) / p.ntn, nt_ = (LIN) - mt_ * p.ntn;                                               \
-        const int m0_ = mt_ * CV_BM, n0_ = nt_ * BN;                                                            \
-        _Pragma("unroll")                                                                                       \
-        for (int i = 0; i < 4; ++i) {                                                                           \
-            const int m = m0_ + lrow + 32 * i;                                                                  \
-            aoff[i] = 0; amask[i] = 0;                                                                          \
-            if (m < p.M) {                                                                                      \
-                if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }                    \
-                /* (n, ho, wo) from m: float reciprocal + one correction step (exact for m < 2^24) */           \
-                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;                                        \
-                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }                    \
-                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;                                        \
-                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }                      \
-                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;                             \
-                aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;                                   \
-                for (int r = 0; r < p.R; ++r)                                                                   \
-                    for (int s2 = 0; s2 < p.S; ++s2)                                                            \
-                        if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W)        \
-                            amask[i] |= 1u << (r * p.S + s2);                                                   \
-            }                                                                                                   \
-        }                                                                                                       \
-        _Pragma("unroll")                                                                                       \
-        for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0_ + lrow + 32 * i) * K + lchunk * 8;         \
-        ld_tap = 0; ld_c = 0; ld_r = 0; ld_s = 0;                                                               \
-    }
+    // named registers (no private-memory arrays): set p, and set q for PF = 2
+    uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    pb2 = pb3 = qb2 = qb3 = make_uint4(0, 0, 0, 0);
+    qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = make_uint4(0, 0, 0, 0);
 
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;              // named registers: no private-memory arrays
-    rb2 = rb3 = make_uint4(0, 0, 0, 0);
-
-#define CV_LOAD_TILE()                                                                                          \
+#define CV_LOAD_TILE(SET)                                                                                         \
     {                                                                                                           \
         const int koff = (ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK;                                            \
         const uint32_t bit = 1u << ld_tap;                                                                      \
         /* out-of-image taps read a dummy in-bounds address (offset 0) and are zeroed after: no divergence */   \
         const bool v0 = amask[0] & bit, v1 = amask[1] & bit, v2 = amask[2] & bit, v3 = amask[3] & bit;          \
-        ra0 = cv_gload(p.x, v0 ? (ptrdiff_t)(aoff[0] + koff) : 0);                                                                \
-        ra1 = cv_gload(p.x, v1 ? (ptrdiff_t)(aoff[1] + koff) : 0);                                                                \
-        ra2 = cv_gload(p.x, v2 ? (ptrdiff_t)(aoff[2] + koff) : 0);                                                                \
-        ra3 = cv_gload(p.x, v3 ? (ptrdiff_t)(aoff[3] + koff) : 0);                                                                \
-        rb0 = cv_gload(wrow[0], 0); wrow[0] += CV_BK;                                                   \
-        rb1 = cv_gload(wrow[1], 0); wrow[1] += CV_BK;                                                   \
+        SET##a0 = cv_gload(p.x, v0 ? (ptrdiff_t)(aoff[0] + koff) : 0);                                            \
+        SET##a1 = cv_gload(p.x, v1 ? (ptrdiff_t)(aoff[1] + koff) : 0);                                            \
+        SET##a2 = cv_gload(p.x, v2 ? (ptrdiff_t)(aoff[2] + koff) : 0);                                            \
+        SET##a3 = cv_gload(p.x, v3 ? (ptrdiff_t)(aoff[3] + koff) : 0);                                            \
+        SET##b0 = cv_gload(wrow[0], 0); wrow[0] += CV_BK;                                                         \
+        SET##b1 = cv_gload(wrow[1], 0); wrow[1] += CV_BK;                                                         \
         if (BROWS == 4) {                                                                                       \
-            rb2 = cv_gload(wrow[BROWS - 2], 0); wrow[BROWS - 2] += CV_BK;                               \
-            rb3 = cv_gload(wrow[BROWS - 1], 0); wrow[BROWS - 1] += CV_BK;                               \
+            SET##b2 = cv_gload(wrow[BROWS - 2], 0); wrow[BROWS - 2] += CV_BK;                                     \
+            SET##b3 = cv_gload(wrow[BROWS - 1], 0); wrow[BROWS - 1] += CV_BK;                                     \
         }                                                                                                       \
         const uint32_t k0 = v0 ? ~0u : 0u, k1 = v1 ? ~0u : 0u, k2 = v2 ? ~0u : 0u, k3 = v3 ? ~0u : 0u;          \
-        ra0.x &= k0; ra0.y &= k0; ra0.z &= k0; ra0.w &= k0; ra1.x &= k1; ra1.y &= k1; ra1.z &= k1; ra1.w &= k1; \
-        ra2.x &= k2; ra2.y &= k2; ra2.z &= k2; ra2.w &= k2; ra3.x &= k3; ra3.y &= k3; ra3.z &= k3; ra3.w &= k3; \
+        SET##a0.x &= k0; SET##a0.y &= k0; SET##a0.z &= k0; SET##a0.w &= k0;                                             \
+        SET##a1.x &= k1; SET##a1.y &= k1; SET##a1.z &= k1; SET##a1.w &= k1;                                             \
+        SET##a2.x &= k2; SET##a2.y &= k2; SET##a2.z &= k2; SET##a2.w &= k2;                                             \
+        SET##a3.x &= k3; SET##a3.y &= k3; SET##a3.z &= k3; SET##a3.w &= k3;                                             \
         if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
     }
 #define CV_ST(base, bytes, row, v) *reinterpret_cast<uint4*>((base) + (bytes) + (row) * CV_ROWB + ((lchunk ^ (((row) >> 1) & 7)) << 4)) = (v)
-#define CV_STORE_TILE(buf)                                                                                      \
+#define CV_STORE_TILE(buf, SET)                                                                                   \
     {                                                                                                           \
-        CV_ST(As, (buf) * A_BYTES, lrow, ra0); CV_ST(As, (buf) * A_BYTES, lrow + 32, ra1);                      \
-        CV_ST(As, (buf) * A_BYTES, lrow + 64, ra2); CV_ST(As, (buf) * A_BYTES, lrow + 96, ra3);                 \
-        CV_ST(Bs, (buf) * B_BYTES, lrow, rb0); CV_ST(Bs, (buf) * B_BYTES, lrow + 32, rb1);                      \
-        if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, lrow + 64, rb2); CV_ST(Bs, (buf) * B_BYTES, lrow + 96, rb3); } \
+        CV_ST(As, (buf) * A_BYTES, lrow, SET##a0); CV_ST(As, (buf) * A_BYTES, lrow + 32, SET##a1);                  \
+        CV_ST(As, (buf) * A_BYTES, lrow + 64, SET##a2); CV_ST(As, (buf) * A_BYTES, lrow + 96, SET##a3);             \
+        CV_ST(Bs, (buf) * B_BYTES, lrow, SET##b0); CV_ST(Bs, (buf) * B_BYTES, lrow + 32, SET##b1);                  \
+        if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, lrow + 64, SET##b2); CV_ST(Bs, (buf) * B_BYTES, lrow + 96, SET##b3); } \
     }
 
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
     const bool dbuf = p.nbuf == 2;
-    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per epilogue staging row
-    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB, over the K-loop buffers)
-    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
-    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
+    // one K-step of MFMAs on LDS stage `buf`: 4 x (4 fragment reads, 4 (or 2) MFMA 32x32x16)
+#define CV_MFMA_STEP(buf)                                                                                       \
+    {                                                                                                           \
+        _Pragma("unroll")                                                                                       \
+        for (int kk = 0; kk < 4; ++kk) {                                                                        \
+            bf16x8 a[MI], b[NI];                                                                                \
+            const int chunk = kk * 2 + fhalf;                                                                   \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi) {                                                                   \
+                const int row = wm * WM + mi * 32 + frow;                                                       \
+                a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+            }                                                                                                   \
+            _Pragma("unroll")                                                                                   \
+            for (int ni = 0; ni < NI; ++ni) {                                                                   \
+                const int row = wn * 64 + ni * 32 + frow;                                                       \
+                b[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+            }                                                                                                   \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi)                                                                     \
+                _Pragma("unroll")                                                                               \
+                for (int ni = 0; ni < NI; ++ni)                                                                 \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+        }                                                                                                       \
+    }
 
-    int lin = cstart + tl;
-    CV_SETUP(lin);
-    CV_LOAD_TILE();
-    for (;;) {
-        const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
-        const int m0 = mt * CV_BM, n0 = nt * BN;
-        const int tl_next = tl + gx;
-        const bool has_next = MODE != 0 && tl_next < clen;
-        f32x16 acc[MI][NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-
-        if (MODE != 0) CV_COORDS();
-        CV_STORE_TILE(0);
+    if (PF == 1) {
+        CV_LOAD_TILE(p);
+        CV_STORE_TILE(0, p);
         __syncthreads();
         for (int kt = 0; kt < p.KT; ++kt) {
             const int buf = dbuf ? (kt & 1) : 0;
             const bool more = kt + 1 < p.KT;
-            if (more) { CV_LOAD_TILE(); }                      // global loads in flight during the MFMAs
-            else if (MODE == 1 && has_next) { CV_SETUP(cstart + tl_next); CV_LOAD_TILE(); }   // ... and during the epilogue
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 a[MI], b[NI];
-                const int chunk = kk * 2 + fhalf;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int row = wm * WM + mi * 32 + frow;
-                    a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int row = wn * 64 + ni * 32 + frow;
-                    b[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
+            if (more) CV_LOAD_TILE(p);                          // global loads in flight during the MFMAs
+            CV_MFMA_STEP(buf);
             if (more) {
-                if (!dbuf) __syncthreads();                  // single stage: everyone is done reading before the overwrite
-                CV_STORE_TILE(dbuf ? (buf ^ 1) : 0);
+                if (!dbuf) __syncthreads();                      // single stage: everyone is done reading before the overwrite
+                CV_STORE_TILE(dbuf ? (buf ^ 1) : 0, p);
             }
             __syncthreads();
         }
-
-        // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
-        // Neighbouring lanes hold neighbouring columns, so lane pairs swap one value per register pair through DPP
-        // (quad_perm [1,0,3,2]) and every lane stores packed bf16x2 dwords: even lanes the even-numbered rows of the
-        // pair, odd lanes the odd ones. Staging rows are padded by 64 B so the two rows of a pair land on disjoint banks.
-        if (MODE != 0) CV_COORDS();
-        float csum[NI], csq[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const uint32_t h0 = cv_f2bf(acc[mi][ni][e]), h1 = cv_f2bf(acc[mi][ni][e + 1]);
-                    const float f0 = __uint_as_float(h0 << 16), f1 = __uint_as_float(h1 << 16);   // statistics of what is stored
-                    csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
-                    const uint32_t send = odd ? h0 : h1;             // what the partner lane needs
-                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
-                    const uint32_t packed = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
-                    const int row = wm * WM + mi * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * fhalf;
-                    const int col = wn * 64 + ni * 32 + (frow & ~1);
-                    *reinterpret_cast<uint32_t*>(Cs + row * CS_STRIDE + col * 2) = packed;
-                }
-        if (MODE == 2 && has_next) { CV_SETUP(cstart + tl_next); CV_LOAD_TILE(); }   // loads issued before the stores below
-        if (p.stats) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
-                csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
-                if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
-            }
-        }
+    } else {
+        // tiles kt+1 (set q) and kt+2 (set p) are in flight while tile kt is multiplied; a set is re-issued as soon
+        // as it has been written to LDS, i.e. two K-steps before it is needed again
+        CV_LOAD_TILE(p);                                        // tile 0
+        if (p.KT > 1) CV_LOAD_TILE(q);                          // tile 1
+        CV_STORE_TILE(0, p);
+        if (p.KT > 2) CV_LOAD_TILE(p);                          // tile 2
         __syncthreads();
-        if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
-            const int which = t / BN, col = t - which * BN;
-            float s = 0.0f;
-            if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
-            else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
-            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
-        }
-#pragma unroll
-        for (int i = 0; i < (CV_BM * CPR) / DIR_TPB; ++i) {
-            const int q = t + DIR_TPB * i, row = q / CPR, ch = q - row * CPR;
-            if (m0 + row < p.M) {
-                uint4 c = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + ch * 16);
-                const size_t go = (size_t)(m0 + row) * p.Cout + n0 + ch * 8;
-                if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
-                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
-                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                    for (int q2 = 0; q2 < 4; ++q2) {
-                        const float lo = __uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16);
-                        const float hi = __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u);
-                        cw[q2] = cv_f2bf(lo) | (cv_f2bf(hi) << 16);
-                    }
-                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-                }
-                if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
-                    const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
-                    const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
-                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int q2 = 0; q2 < 4; ++q2) {
-                        if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
-                        if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
-                    }
-                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-                }
-                *reinterpret_cast<uint4*>(p.y + go) = c;
+        const int odd_buf = dbuf ? 1 : 0;
+        for (int kt = 0; kt < p.KT; kt += 2) {
+            CV_MFMA_STEP(0);                                    // tile kt
+            if (kt + 1 < p.KT) {
+                if (!dbuf) __syncthreads();
+                CV_STORE_TILE(odd_buf, q);                      // tile kt + 1
+                if (kt + 3 < p.KT) CV_LOAD_TILE(q);             // tile kt + 3
             }
+            __syncthreads();
+            if (kt + 1 >= p.KT) break;
+            CV_MFMA_STEP(odd_buf);                              // tile kt + 1
+            if (kt + 2 < p.KT) {
+                if (!dbuf) __syncthreads();
+                CV_STORE_TILE(0, p);                            // tile kt + 2
+                if (kt + 4 < p.KT) CV_LOAD_TILE(p);             // tile kt + 4
+            }
+            __syncthreads();
         }
-        if (!has_next) break;
-        tl = tl_next;
-        lin = cstart + tl;
-        __syncthreads();                                       // staging reads done before the next tile lands in LDS
     }
-#undef CV_SETUP
-#undef CV_COORDS
+#undef CV_MFMA_STEP
 #undef CV_LOAD_TILE
 #undef CV_STORE_TILE
 #undef CV_ST
+
+    // ---- epilogue: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free now) -> 16-B row stores
+    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row (padding: rows r, r+4 on disjoint banks)
+    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
+    float csum[NI], csq[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
+    unsigned char* cbase = Cs + (wm * WM + 4 * fhalf) * CS_STRIDE + (wn * 64 + frow) * 2;
+    if (p.stats) cv_stage_acc<MI, NI, CS_STRIDE, true>(acc, cbase, csum, csq);
+    else cv_stage_acc<MI, NI, CS_STRIDE, false>(acc, cbase, csum, csq);
+    if (p.stats) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
+            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
+            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
+        }
+    }
+    __syncthreads();
+    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
+        const int which = t / BN, col = t - which * BN;
+        float s = 0.0f;
+        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
+        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
+        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
+    }
+    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
+    constexpr int RPI = DIR_TPB / CPR;                          // rows per pass of the workgroup
+    const int srow = t / CPR, sch = t - srow * CPR;
+    const unsigned char* cs = Cs + srow * CS_STRIDE + sch * 16;
+    size_t go = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
+    const size_t gstep = (size_t)RPI * p.Cout;
+    const bool full = m0 + CV_BM <= p.M;
+#pragma unroll
+    for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
+        if (full || m0 + srow + i * RPI < p.M) {
+            uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
+                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
+                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2)
+                    cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                          __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            }
+            if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
+                const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
+                const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
+                    if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                }
+                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            }
+            *reinterpret_cast<uint4*>(p.y + go) = c;
+        }
+    }
 }
 
 }  // namespace
@@ -359,27 +380,21 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
     static const int force_nbuf = []() { const char* e = getenv("DIR_CONV_NBUF"); return e ? atoi(e) : 0; }();
     static const int nbuf_kt = []() { const char* e = getenv("DIR_CONV_NBUF_KT"); return e ? atoi(e) : 18; }();
     p.nbuf = force_nbuf ? force_nbuf : (p.KT <= nbuf_kt ? 1 : 2);
-    // Grid: DIR_CONV_MODE=0 launches one workgroup per tile; 1 / 2 launch DIR_CONV_PER_CU workgroups per CU that loop
-    // over tiles (see the kernel's MODE).
-    static const int mode = []() { const char* e = getenv("DIR_CONV_MODE"); return e ? atoi(e) : 0; }();
-    static const int per_cu_env = []() { const char* e = getenv("DIR_CONV_PER_CU"); return e ? atoi(e) : 0; }();
-    static const int ncu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev);
-                                  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    // Prefetch distance: 2 K-tiles in flight per workgroup once the loop is long enough to use them (DIR_CONV_PF=1|2
+    // overrides, DIR_CONV_PF_KT = shortest loop that gets PF = 2).
+    static const int force_pf = []() { const char* e = getenv("DIR_CONV_PF"); return e ? atoi(e) : 0; }();
+    static const int pf_kt = []() { const char* e = getenv("DIR_CONV_PF_KT"); return e ? atoi(e) : 36; }();
+    const int pf = force_pf ? force_pf : (p.KT >= pf_kt ? 2 : 1);
     const int bn = wide ? 128 : 64;
     const int stage = CV_BM * (bn * 2 + 64) + 2048;                 // epilogue staging + column partials
     const int loop = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
     const int lds = loop > stage ? loop : stage;
-    int per_cu = per_cu_env > 0 ? per_cu_env : (160 * 1024) / lds;
-    if (per_cu > 4) per_cu = 4;
-    int grid = p.nblocks;
-    if (mode != 0 && (long long)ncu * per_cu < grid) grid = ncu * per_cu;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
     (void)once;
-#define CV_LAUNCH(BN_, MODE_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE_>), dim3(grid), dim3(DIR_TPB), lds, s, p)
-    if (wide) { if (mode == 1) CV_LAUNCH(128, 1); else if (mode == 2) CV_LAUNCH(128, 2); else CV_LAUNCH(128, 0); }
-    else      { if (mode == 1) CV_LAUNCH(64, 1);  else if (mode == 2) CV_LAUNCH(64, 2);  else CV_LAUNCH(64, 0); }
+#define CV_LAUNCH(BN_, PF_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, PF_>), dim3(p.nblocks), dim3(DIR_TPB), lds, s, p)
+    if (wide) { if (pf == 2) CV_LAUNCH(128, 2); else CV_LAUNCH(128, 1); }
+    else      { if (pf == 2) CV_LAUNCH(64, 2);  else CV_LAUNCH(64, 1); }
 #undef CV_LAUNCH
     DIR_LAUNCH_CHECK();
     return DIR_OK;

@@ -23,7 +23,6 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
 
 struct WgP {
     const uint16_t* dy; const uint16_t* x; float* part;
@@ -31,47 +30,55 @@ struct WgP {
     int M, RS, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split;
     float inv_wo, inv_ho;
     int simple;               // 1x1, stride 1, pad 0: gathered row == m
+    // incremental im2col walk (see WgWalk): extents in input-pixel units and byte corrections of the running offset
+    int WoS, HoS;             // Wo * stride, Ho * stride
+    int c1, c2;               // added when the walk wraps to the next image row / the next image
+    int dws64, dhs64, dn64, c64;   // one K-step = 64 rows further
+    int cstep;                // one row further
 };
 
 constexpr int WG_BK = 64, WG_ROWB = 128;
+constexpr int WG_OOB = (int)0x80000000;            // buffer-load offset beyond any tensor: the load returns zeros
 
-__device__ __forceinline__ u32x4 wg_gload(const uint16_t* base, ptrdiff_t off) {
-    return *reinterpret_cast<gvec_ptr>(reinterpret_cast<uintptr_t>(base + off));
-}
 __device__ __forceinline__ int wg_swz(int row, int chunk) { return chunk ^ (((row >> 1) ^ (row >> 4)) & 7); }
 
-// Row m = (n, ho, wo) of the implicit im2col matrix for filter tap (tr, ts): 16 B of X or zeros outside the image.
-// Integer divisions by Wo / Ho are a float multiply plus one correction step (exact for m < 2^24).
-__device__ __forceinline__ u32x4 wg_gather(const WgP& p, int mm, int tr, int ts, int coff) {
-    int q1 = (int)((float)mm * p.inv_wo); int wo = mm - q1 * p.Wo;
-    if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-    int n = (int)((float)q1 * p.inv_ho); int ho = q1 - n * p.Ho;
-    if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-    const int hi = ho * p.stride - p.pad + tr, wi = wo * p.stride - p.pad + ts;
-    const bool ok = mm < p.M && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-    const ptrdiff_t o = ok ? ((ptrdiff_t)((n * p.H + hi) * p.W + wi) * p.Cin + coff) : 0;
-    const u32x4 v = wg_gload(p.x, o);
-    const uint32_t k = ok ? ~0u : 0u;
-    return v & k;
+// Position of one im2col row m = (n, ho, wo) for a fixed filter tap, kept incrementally: hs = ho * stride,
+// ws = wo * stride and `off` = byte offset of X[n, hs + tr - pad, ws + ts - pad, ci0 + 8 cb]. Moving d rows further is
+// mixed-radix addition with two carries; the offset moves by a constant plus a constant per carry — no division
+// and no multiplication per row (the decode by reciprocals happens once per workgroup).
+struct WgWalk { int n, hs, ws, off; };
+__device__ __forceinline__ void wg_advance(WgWalk& w, const WgP& p, int dws, int dhs, int dn, int cbase) {
+    w.ws += dws;
+    const bool c1 = w.ws >= p.WoS;
+    w.ws -= c1 ? p.WoS : 0;
+    w.hs += dhs + (c1 ? p.stride : 0);
+    const bool c2 = w.hs >= p.HoS;
+    w.hs -= c2 ? p.HoS : 0;
+    w.n += dn + (c2 ? 1 : 0);
+    w.off += cbase + (c1 ? p.c1 : 0) + (c2 ? p.c2 : 0);
+}
+// 16 B of X for the row at `w` (zeros outside the image or past the last row: the buffer load is sent out of range)
+__device__ __forceinline__ u32x4 wg_gather(__amdgpu_buffer_rsrc_t rx, const WgWalk& w, const WgP& p, int trp, int tsp) {
+    const bool ok = (unsigned)(w.hs + trp) < (unsigned)p.H && (unsigned)(w.ws + tsp) < (unsigned)p.W && w.n < p.N;
+    return __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? w.off : WG_OOB, 0, 0);
 }
 
-// 4 rows x 8 channels (4 x 16 B) -> 8 channels x 4 k, written as 8-byte pieces into the [channel][k] tile.
-__device__ __forceinline__ void wg_transpose_store(unsigned char* tile, int ch0, int rg, const u32x4& r0, const u32x4& r1,
+// 4 rows x 8 channels (4 x 16 B) -> 8 channels x 4 k, written as 8-byte pieces into the [channel][k] tile at the
+// per-thread byte offsets o[0..7] (rows ch0 + 0..7).
+__device__ __forceinline__ void wg_transpose_store(unsigned char* tile, const uint32_t (&o)[8], const u32x4& r0, const u32x4& r1,
                                                    const u32x4& r2, const u32x4& r3) {
-    const int chunk = rg >> 1, half = (rg & 1) * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // v_perm_b32(src0 = high dword, src1 = low dword): 0x05040100 -> lo16(src1) | lo16(src0) << 16
         const uint32_t lo01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x05040100u), lo23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x05040100u);
         const uint32_t hi01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x07060302u), hi23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x07060302u);
-        const int row_lo = ch0 + 2 * q, row_hi = row_lo + 1;
-        *reinterpret_cast<uint2*>(tile + row_lo * WG_ROWB + (wg_swz(row_lo, chunk) << 4) + half) = make_uint2(lo01, lo23);
-        *reinterpret_cast<uint2*>(tile + row_hi * WG_ROWB + (wg_swz(row_hi, chunk) << 4) + half) = make_uint2(hi01, hi23);
+        *reinterpret_cast<uint2*>(tile + o[2 * q]) = make_uint2(lo01, lo23);
+        *reinterpret_cast<uint2*>(tile + o[2 * q + 1]) = make_uint2(hi01, hi23);
     }
 }
 
 template <int TM, int TN>
-__global__ void __launch_bounds__(DIR_TPB)
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(2)))
 conv_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = TM * WG_ROWB, B_BYTES = TN * WG_ROWB;
@@ -93,8 +100,10 @@ conv_wgrad_kernel(WgP p) {
     const int tm = b % p.tiles_m; b /= p.tiles_m;
     const int split = b;
     const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int trp = tr - p.pad, tsp = ts - p.pad;
     const int co0 = tm * TM, ci0 = tn * TN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
 
     const int ks0 = split * p.ksteps_per_split;
     int ks1 = ks0 + p.ksteps_per_split; if (ks1 > p.ksteps_total) ks1 = p.ksteps_total;
@@ -103,38 +112,107 @@ conv_wgrad_kernel(WgP p) {
     const bool doA = t < 2 * TM, doB = t < 2 * TN;
     const int ca = t % CA, ga = t / CA, cb = t % CB, gb = t / CB;
 
-    u32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
+    // ---- everything that depends only on the thread is computed once and pinned in registers: the K loop then issues
+    // loads, permutes, LDS accesses and MFMAs with (almost) no address arithmetic. (Left to itself the compiler
+    // re-derives the swizzled LDS addresses every K-step: ~450 VALU instructions per 16 MFMAs, i.e. VALU bound.)
+    uint32_t aw[8], bw[8];                                        // transposing stores
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int ra = ca * 8 + q, rb = cb * 8 + q;
+        aw[q] = ra * WG_ROWB + (wg_swz(ra, ga >> 1) << 4) + (ga & 1) * 8;
+        bw[q] = rb * WG_ROWB + (wg_swz(rb, gb >> 1) << 4) + (gb & 1) * 8;
+        asm volatile("" : "+v"(aw[q])); asm volatile("" : "+v"(bw[q]));
+    }
+    uint32_t af[MI][4], bf[NI][4];                                // fragment reads
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (TM / 2) + mi * 32 + frow;
+            af[mi][kk] = row * WG_ROWB + (wg_swz(row, kk * 2 + fhalf) << 4);
+            asm volatile("" : "+v"(af[mi][kk]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = wn * (TN / 2) + ni * 32 + frow;
+            bf[ni][kk] = row * WG_ROWB + (wg_swz(row, kk * 2 + fhalf) << 4);
+            asm volatile("" : "+v"(bf[ni][kk]));
+        }
+    }
+    // global byte offsets inside one K-step's 64 rows (the K-step itself is a wave-uniform soffset)
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), (short)0, (int)((unsigned)p.M * (unsigned)p.Cout * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0, (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin * 2u), 0x00020000);
+    int voa[4], vob[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        voa[j] = ((4 * ga + j) * p.Cout + co0 + ca * 8) * 2;
+        vob[j] = ((4 * gb + j) * p.Cin + ci0 + cb * 8) * 2;       // simple (1x1, stride 1) case: row m of X is row m of the GEMM
+        asm volatile("" : "+v"(voa[j])); asm volatile("" : "+v"(vob[j]));
+    }
+    WgWalk walk = {0, 0, 0, 0};
+    if (!p.simple && doB) {                                       // decode the first row of this thread once
+        const int mm = ks0 * WG_BK + 4 * gb;
+        int q1 = (int)((float)mm * p.inv_wo); int wo = mm - q1 * p.Wo;
+        if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+        int n = (int)((float)q1 * p.inv_ho); int ho = q1 - n * p.Ho;
+        if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+        walk.n = n; walk.hs = ho * p.stride; walk.ws = wo * p.stride;
+        walk.off = (((n * p.H + walk.hs + trp) * p.W + walk.ws + tsp) * p.Cin + ci0 + cb * 8) * 2;
+    }
 
+    u32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+    a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = (u32x4){0u, 0u, 0u, 0u};
+
+#define WG_BL(rs, vo, so) __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)
 #define WG_LOAD(ks)                                                                                               \
     {                                                                                                             \
-        const int mbase = (ks) * WG_BK;                                                                           \
+        const int mrem = p.M - (ks) * WG_BK;                      /* rows left from this K-step's first row */    \
+        const bool full = mrem >= WG_BK;                                                                          \
         if (doA) {                                                                                                \
-            const int m = mbase + 4 * ga;                                                                         \
-            const ptrdiff_t o = (ptrdiff_t)m * p.Cout + co0 + ca * 8;                                             \
-            a0 = (m + 0 < p.M) ? wg_gload(p.dy, o) : zero;                                                        \
-            a1 = (m + 1 < p.M) ? wg_gload(p.dy, o + p.Cout) : zero;                                               \
-            a2 = (m + 2 < p.M) ? wg_gload(p.dy, o + 2 * (ptrdiff_t)p.Cout) : zero;                                \
-            a3 = (m + 3 < p.M) ? wg_gload(p.dy, o + 3 * (ptrdiff_t)p.Cout) : zero;                                \
+            const int so = (ks) * WG_BK * p.Cout * 2;                                                             \
+            a0 = WG_BL(rs_dy, (full || 4 * ga + 0 < mrem) ? voa[0] : WG_OOB, so);                                 \
+            a1 = WG_BL(rs_dy, (full || 4 * ga + 1 < mrem) ? voa[1] : WG_OOB, so);                                 \
+            a2 = WG_BL(rs_dy, (full || 4 * ga + 2 < mrem) ? voa[2] : WG_OOB, so);                                 \
+            a3 = WG_BL(rs_dy, (full || 4 * ga + 3 < mrem) ? voa[3] : WG_OOB, so);                                 \
         }                                                                                                         \
         if (doB) {                                                                                                \
-            const int m = mbase + 4 * gb;                                                                         \
             if (p.simple) {                                                                                       \
-                const ptrdiff_t o = (ptrdiff_t)m * p.Cin + ci0 + cb * 8;                                          \
-                b0 = (m + 0 < p.M) ? wg_gload(p.x, o) : zero;                                                     \
-                b1 = (m + 1 < p.M) ? wg_gload(p.x, o + p.Cin) : zero;                                             \
-                b2 = (m + 2 < p.M) ? wg_gload(p.x, o + 2 * (ptrdiff_t)p.Cin) : zero;                              \
-                b3 = (m + 3 < p.M) ? wg_gload(p.x, o + 3 * (ptrdiff_t)p.Cin) : zero;                              \
+                const int so = (ks) * WG_BK * p.Cin * 2;                                                          \
+                b0 = WG_BL(rs_x, (full || 4 * gb + 0 < mrem) ? vob[0] : WG_OOB, so);                              \
+                b1 = WG_BL(rs_x, (full || 4 * gb + 1 < mrem) ? vob[1] : WG_OOB, so);                              \
+                b2 = WG_BL(rs_x, (full || 4 * gb + 2 < mrem) ? vob[2] : WG_OOB, so);                              \
+                b3 = WG_BL(rs_x, (full || 4 * gb + 3 < mrem) ? vob[3] : WG_OOB, so);                              \
             } else {                                                                                              \
-                b0 = wg_gather(p, m + 0, tr, ts, ci0 + cb * 8); b1 = wg_gather(p, m + 1, tr, ts, ci0 + cb * 8);       \
-                b2 = wg_gather(p, m + 2, tr, ts, ci0 + cb * 8); b3 = wg_gather(p, m + 3, tr, ts, ci0 + cb * 8);       \
+                WgWalk w = walk;                                                                                  \
+                b0 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
+                b1 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
+                b2 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
+                b3 = wg_gather(rs_x, w, p, trp, tsp);                                                             \
+                wg_advance(walk, p, p.dws64, p.dhs64, p.dn64, p.c64);                                             \
             }                                                                                                     \
         }                                                                                                         \
     }
 #define WG_STORE(buf)                                                                                             \
     {                                                                                                             \
-        if (doA) wg_transpose_store(As + (buf) * A_BYTES, ca * 8, ga, a0, a1, a2, a3);                            \
-        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, cb * 8, gb, b0, b1, b2, b3);                            \
+        if (doA) wg_transpose_store(As + (buf) * A_BYTES, aw, a0, a1, a2, a3);                                    \
+        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, bw, b0, b1, b2, b3);                                    \
+    }
+    // one K-step on LDS stage `buf` (a literal: the stage offset folds into the instructions' immediate offsets)
+#define WG_MFMA_STEP(buf)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll")                                                                                         \
+        for (int kk = 0; kk < 4; ++kk) {                                                                          \
+            bf16x8 a[MI], bb[NI];                                                                                 \
+            _Pragma("unroll")                                                                                     \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + af[mi][kk]); \
+            _Pragma("unroll")                                                                                     \
+            for (int ni = 0; ni < NI; ++ni) bb[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + bf[ni][kk]); \
+            _Pragma("unroll")                                                                                     \
+            for (int mi = 0; mi < MI; ++mi)                                                                       \
+                _Pragma("unroll")                                                                                 \
+                for (int ni = 0; ni < NI; ++ni)                                                                   \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);   \
+        }                                                                                                         \
     }
 
     f32x16 acc[MI][NI];
@@ -145,53 +223,40 @@ conv_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    const int frow = lane & 31, fhalf = lane >> 5;
     if (ks0 < ks1) {
         WG_LOAD(ks0);
         WG_STORE(0);
         __syncthreads();
-        for (int ks = ks0; ks < ks1; ++ks) {
-            const int buf = (ks - ks0) & 1;
-            const bool more = ks + 1 < ks1;
-            if (more) WG_LOAD(ks + 1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 a[MI], bb[NI];
-                const int chunk = kk * 2 + fhalf;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int row = wm * (TM / 2) + mi * 32 + frow;
-                    a[mi] = *reinterpret_cast<const bf16x8*>(As + buf * A_BYTES + row * WG_ROWB + (wg_swz(row, chunk) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int row = wn * (TN / 2) + ni * 32 + frow;
-                    bb[ni] = *reinterpret_cast<const bf16x8*>(Bs + buf * B_BYTES + row * WG_ROWB + (wg_swz(row, chunk) << 4));
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
-            }
-            if (more) WG_STORE(buf ^ 1);
+        for (int ks = ks0; ks < ks1; ks += 2) {                  // two K-steps per trip: stages 0 and 1 are literals
+            if (ks + 1 < ks1) WG_LOAD(ks + 1);                   // global loads in flight during the MFMAs
+            WG_MFMA_STEP(0);
+            if (ks + 1 >= ks1) break;
+            WG_STORE(1);
+            __syncthreads();
+            if (ks + 2 < ks1) WG_LOAD(ks + 2);
+            WG_MFMA_STEP(1);
+            if (ks + 2 < ks1) WG_STORE(0);
             __syncthreads();
         }
     }
+#undef WG_BL
 #undef WG_LOAD
 #undef WG_STORE
+#undef WG_MFMA_STEP
 
     // partial[split][co][tap][ci] (fp32). C/D: col = lane & 31 -> ci, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -> co.
-    float* out = p.part + (size_t)split * p.Cout * p.RS * p.Cin;
+    // Address = wave-uniform pointer (split, tile, register index) + one per-thread 32-bit offset.
+    const int rsc = p.RS * p.Cin;
+    float* out = p.part + (size_t)split * p.Cout * rsc + (size_t)co0 * rsc + (size_t)tap * p.Cin + ci0;
+    const uint32_t toff = (uint32_t)((wm * (TM / 2) + 4 * fhalf) * rsc + wn * (TN / 2) + frow);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wm * (TM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-                const int ci = ci0 + wn * (TN / 2) + ni * 32 + frow;
-                out[((size_t)co * p.RS + tap) * p.Cin + ci] = acc[mi][ni][e];
+                float* ob = out + (size_t)(mi * 32 + (e & 3) + 8 * (e >> 2)) * rsc + ni * 32;
+                ob[toff] = acc[mi][ni][e];
             }
 }
 
@@ -267,7 +332,7 @@ extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     const long long M = (long long)N * Ho * Wo;
-    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 30), DIR_EUNSUPPORTED);   // 32-bit byte offsets
     const WgPlan pl = wg_plan(M, Cin, Cout, R * S);
     DIR_RETURN_IF(workspace_bytes < pl.ws_bytes, DIR_EWORKSPACE);
     WgP p;
@@ -277,6 +342,15 @@ extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
     p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
     p.inv_wo = 1.0f / (float)Wo; p.inv_ho = 1.0f / (float)Ho;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    {   // constants of the incremental im2col walk (bytes of bf16 X)
+        const int dw = WG_BK % Wo, dh = (WG_BK / Wo) % Ho, dn = WG_BK / (Wo * Ho);
+        p.WoS = Wo * stride; p.HoS = Ho * stride;
+        p.c1 = (stride * W - Wo * stride) * Cin * 2;
+        p.c2 = (H * W - Ho * stride * W) * Cin * 2;
+        p.dws64 = dw * stride; p.dhs64 = dh * stride; p.dn64 = dn;
+        p.c64 = (dn * H * W + dh * stride * W + dw * stride) * Cin * 2;
+        p.cstep = stride * Cin * 2;
+    }
     const int nblocks = pl.splits * pl.tiles_m * pl.tiles_n * p.RS;
     hipStream_t s = dir_s(stream);
     if (pl.tm == 128 && pl.tn == 128) wg_launch<128, 128>(p, nblocks, s);

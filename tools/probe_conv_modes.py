@@ -31,5 +31,14 @@ for cin,cout,k,st,h,cnt in SH:
         td=ev(lambda: conv2d_igemm(dy,wr,1,pad))
         tot_d+=td*cnt
     rows.append(f"{cin:5d}->{cout:5d} k{k} s{st} H{h:3d} x{cnt} | fwd {tf*1e3:8.1f}us | dgrad {td*1e3:8.1f}us")
-print(f"[{tag or 'default'}] B={B} fwd {tot_f:.3f} ms  dgrad(stride-1) {tot_d:.3f} ms")
+from dirhip.conv import conv2d_wgrad
+tot_w=0
+for idx,(cin,cout,k,st,h,cnt) in enumerate(SH):
+    pad=k//2; ho=(h+2*pad-k)//st+1
+    x=torch.randn(B,cin,h,h,device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy=torch.randn(B,cout,ho,ho,device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    tw=ev(lambda: conv2d_wgrad(dy,x,k,st,pad))
+    tot_w+=tw*cnt
+    rows[idx]+=f" | wgrad {tw*1e3:8.1f}us"
+print(f"[{tag or 'default'}] B={B} fwd {tot_f:.3f} ms  dgrad(stride-1) {tot_d:.3f} ms  wgrad {tot_w:.3f} ms")
 if os.environ.get("PROBE_ROWS"): print("\n".join(rows))
