@@ -26,12 +26,6 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;        // explicit global address space (no flat loads)
-__device__ __forceinline__ uint4 cv_gload(const uint16_t* base, ptrdiff_t elem_off) {
-    const u32x4 v = *reinterpret_cast<gvec_ptr>(reinterpret_cast<uintptr_t>(base + elem_off));
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
 struct ConvP {
     const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
     const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
@@ -44,6 +38,7 @@ struct ConvP {
 };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
+constexpr int CV_OOB = (int)0x80000000;                         // buffer-load offset beyond any tensor: the load returns zeros
 
 __device__ __forceinline__ uint32_t cv_f2bf(float f) {
     uint32_t u = __float_as_uint(f);
@@ -87,7 +82,7 @@ __device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsign
 // throughput: a 32 KB K-tile takes > 1 us to arrive under load while its 16 MFMAs per wavefront take 0.2 us, so the
 // rate is (bytes in flight per CU) / latency. PF = 2 keeps two K-tiles per workgroup in flight in two register sets
 // (p, q) for 32 more VGPRs (2 instead of 3 wavefronts per SIMD, which the 64 KB two-stage LDS image allows anyway).
-template <int BN, int PF>
+template <int BN, int PF, int NBUF>
 __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(PF == 1 ? 3 : 2)))
 conv_igemm_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -97,8 +92,9 @@ conv_igemm_kernel(ConvP p) {
     constexpr int MI = (BN == 128) ? 2 : 1;               // 32x32 tiles per wavefront along M
     constexpr int NI = 2;                                 //                      ... along N
     constexpr int WM = MI * 32;
+    constexpr bool dbuf = NBUF == 2;                      // LDS stages: 2 = next tile written while the current one is read
     unsigned char* As = smem;
-    unsigned char* Bs = smem + p.nbuf * A_BYTES;
+    unsigned char* Bs = smem + NBUF * A_BYTES;
 
     // ---- workgroup -> (m tile, n tile), XCD-aware and bijective: the hardware deals workgroup b to XCD b % 8, so the
     // linear tile space is cut into 8 contiguous chunks and the N-tiles of one M-tile run on the same XCD (the A-tile
@@ -113,10 +109,12 @@ conv_igemm_kernel(ConvP p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (BN == 128) ? (wave >> 1) : wave;
     const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int frow = lane & 31, fhalf = lane >> 5;
 
     // ---- loader coordinates: thread loads the 16-B chunk (t & 7) of rows (t >> 3) + 32 i.
-    // Everything position dependent is computed ONCE: per row a signed element offset of its (hi0, wi0) pixel and a
-    // bit mask of the filter taps that fall inside the image; per K-step only a wave-uniform offset is added.
+    // Everything position dependent is computed ONCE: per row the signed byte offset of its (hi0, wi0) pixel and a bit
+    // mask of the filter taps that fall inside the image; per K-step a wave-uniform offset is added and out-of-image
+    // taps are sent out of the buffer's range (the buffer load then returns zeros: no masking instructions).
     const int lrow = t >> 3, lchunk = t & 7;
     int aoff[4];
     uint32_t amask[4];
@@ -125,61 +123,78 @@ conv_igemm_kernel(ConvP p) {
         const int m = m0 + lrow + 32 * i;
         aoff[i] = 0; amask[i] = 0;
         if (m < p.M) {
-            if (p.simple) { aoff[i] = m * p.Cin + lchunk * 8; amask[i] = 1u; continue; }
+            if (p.simple) { aoff[i] = (m * p.Cin + lchunk * 8) * 2; amask[i] = 1u; continue; }
             // (n, ho, wo) from m: float reciprocal + one correction step instead of integer divisions (exact for m < 2^24)
             int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
             if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
             int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
             if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            aoff[i] = ((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8;
+            aoff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + lchunk * 8) * 2;
             for (int r = 0; r < p.R; ++r)
                 for (int s2 = 0; s2 < p.S; ++s2)
                     if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
         }
     }
-    const size_t K = (size_t)p.KT * CV_BK;
-    const uint16_t* wrow[BROWS];
+    const int K = p.KT * CV_BK;
+    int woff[BROWS];                                       // byte offset of this thread's chunk in weight row n0 + lrow + 32 i
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (size_t)(n0 + lrow + 32 * i) * K + lchunk * 8;
+    for (int i = 0; i < BROWS; ++i) woff[i] = ((n0 + lrow + 32 * i) * K + lchunk * 8) * 2;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0,
+                                                                           (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), (short)0,
+                                                                           (int)((unsigned)p.Cout * (unsigned)K * 2u), 0x00020000);
+    // LDS byte offsets, pinned in registers: one for the loader's stores (rows + 32 i are immediates; the swizzle of
+    // row lrow + 32 i equals that of lrow) and one per fragment read of a K-step
+    uint32_t st_off = lrow * CV_ROWB + ((lchunk ^ ((lrow >> 1) & 7)) << 4);
+    asm volatile("" : "+v"(st_off));
+    uint32_t af[MI][4], bf[NI][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * WM + mi * 32 + frow;
+            af[mi][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(af[mi][kk]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = wn * 64 + ni * 32 + frow;
+            bf[ni][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(bf[ni][kk]));
+        }
+    }
 
-    // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch
-    int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0;
+    // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch, and its index
+    int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0, ld_k = 0;
     // named registers (no private-memory arrays): set p, and set q for PF = 2
-    uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
-    pb2 = pb3 = qb2 = qb3 = make_uint4(0, 0, 0, 0);
-    qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = make_uint4(0, 0, 0, 0);
+    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = (u32x4){0u, 0u, 0u, 0u};
+    qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = (u32x4){0u, 0u, 0u, 0u};
 
-#define CV_LOAD_TILE(SET)                                                                                         \
+#define CV_BL(rs, vo, so) __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)
+#define CV_LOAD_TILE(SET)                                                                                       \
     {                                                                                                           \
-        const int koff = (ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK;                                            \
+        const int koff = ((ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK) * 2;                                      \
         const uint32_t bit = 1u << ld_tap;                                                                      \
-        /* out-of-image taps read a dummy in-bounds address (offset 0) and are zeroed after: no divergence */   \
-        const bool v0 = amask[0] & bit, v1 = amask[1] & bit, v2 = amask[2] & bit, v3 = amask[3] & bit;          \
-        SET##a0 = cv_gload(p.x, v0 ? (ptrdiff_t)(aoff[0] + koff) : 0);                                            \
-        SET##a1 = cv_gload(p.x, v1 ? (ptrdiff_t)(aoff[1] + koff) : 0);                                            \
-        SET##a2 = cv_gload(p.x, v2 ? (ptrdiff_t)(aoff[2] + koff) : 0);                                            \
-        SET##a3 = cv_gload(p.x, v3 ? (ptrdiff_t)(aoff[3] + koff) : 0);                                            \
-        SET##b0 = cv_gload(wrow[0], 0); wrow[0] += CV_BK;                                                         \
-        SET##b1 = cv_gload(wrow[1], 0); wrow[1] += CV_BK;                                                         \
-        if (BROWS == 4) {                                                                                       \
-            SET##b2 = cv_gload(wrow[BROWS - 2], 0); wrow[BROWS - 2] += CV_BK;                                     \
-            SET##b3 = cv_gload(wrow[BROWS - 1], 0); wrow[BROWS - 1] += CV_BK;                                     \
-        }                                                                                                       \
-        const uint32_t k0 = v0 ? ~0u : 0u, k1 = v1 ? ~0u : 0u, k2 = v2 ? ~0u : 0u, k3 = v3 ? ~0u : 0u;          \
-        SET##a0.x &= k0; SET##a0.y &= k0; SET##a0.z &= k0; SET##a0.w &= k0;                                             \
-        SET##a1.x &= k1; SET##a1.y &= k1; SET##a1.z &= k1; SET##a1.w &= k1;                                             \
-        SET##a2.x &= k2; SET##a2.y &= k2; SET##a2.z &= k2; SET##a2.w &= k2;                                             \
-        SET##a3.x &= k3; SET##a3.y &= k3; SET##a3.z &= k3; SET##a3.w &= k3;                                             \
+        SET##a0 = CV_BL(rs_x, (amask[0] & bit) ? aoff[0] + koff : CV_OOB, 0);                                   \
+        SET##a1 = CV_BL(rs_x, (amask[1] & bit) ? aoff[1] + koff : CV_OOB, 0);                                   \
+        SET##a2 = CV_BL(rs_x, (amask[2] & bit) ? aoff[2] + koff : CV_OOB, 0);                                   \
+        SET##a3 = CV_BL(rs_x, (amask[3] & bit) ? aoff[3] + koff : CV_OOB, 0);                                   \
+        const int wso = ld_k * CV_BK * 2;                          /* wave-uniform: the K-step inside the weight rows */ \
+        SET##b0 = CV_BL(rs_w, woff[0], wso);                                                                    \
+        SET##b1 = CV_BL(rs_w, woff[1], wso);                                                                    \
+        if (BROWS == 4) { SET##b2 = CV_BL(rs_w, woff[BROWS - 2], wso); SET##b3 = CV_BL(rs_w, woff[BROWS - 1], wso); } \
+        ++ld_k;                                                                                                 \
         if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
     }
-#define CV_ST(base, bytes, row, v) *reinterpret_cast<uint4*>((base) + (bytes) + (row) * CV_ROWB + ((lchunk ^ (((row) >> 1) & 7)) << 4)) = (v)
-#define CV_STORE_TILE(buf, SET)                                                                                   \
+#define CV_ST(base, bytes, i, v) *reinterpret_cast<u32x4*>((base) + (bytes) + (i) * 32 * CV_ROWB + st_off) = (v)
+#define CV_STORE_TILE(buf, SET)                                                                                 \
     {                                                                                                           \
-        CV_ST(As, (buf) * A_BYTES, lrow, SET##a0); CV_ST(As, (buf) * A_BYTES, lrow + 32, SET##a1);                  \
-        CV_ST(As, (buf) * A_BYTES, lrow + 64, SET##a2); CV_ST(As, (buf) * A_BYTES, lrow + 96, SET##a3);             \
-        CV_ST(Bs, (buf) * B_BYTES, lrow, SET##b0); CV_ST(Bs, (buf) * B_BYTES, lrow + 32, SET##b1);                  \
-        if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, lrow + 64, SET##b2); CV_ST(Bs, (buf) * B_BYTES, lrow + 96, SET##b3); } \
+        CV_ST(As, (buf) * A_BYTES, 0, SET##a0); CV_ST(As, (buf) * A_BYTES, 1, SET##a1);                         \
+        CV_ST(As, (buf) * A_BYTES, 2, SET##a2); CV_ST(As, (buf) * A_BYTES, 3, SET##a3);                         \
+        CV_ST(Bs, (buf) * B_BYTES, 0, SET##b0); CV_ST(Bs, (buf) * B_BYTES, 1, SET##b1);                         \
+        if (BROWS == 4) { CV_ST(Bs, (buf) * B_BYTES, 2, SET##b2); CV_ST(Bs, (buf) * B_BYTES, 3, SET##b3); }     \
     }
 
     f32x16 acc[MI][NI];
@@ -190,25 +205,17 @@ conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const bool dbuf = p.nbuf == 2;
-    // one K-step of MFMAs on LDS stage `buf`: 4 x (4 fragment reads, 4 (or 2) MFMA 32x32x16)
+    // one K-step of MFMAs on LDS stage `buf` (a literal: the stage folds into the instructions' immediate offsets):
+    // 4 x (4 fragment reads, 4 (or 2) MFMA 32x32x16)
 #define CV_MFMA_STEP(buf)                                                                                       \
     {                                                                                                           \
         _Pragma("unroll")                                                                                       \
         for (int kk = 0; kk < 4; ++kk) {                                                                        \
             bf16x8 a[MI], b[NI];                                                                                \
-            const int chunk = kk * 2 + fhalf;                                                                   \
             _Pragma("unroll")                                                                                   \
-            for (int mi = 0; mi < MI; ++mi) {                                                                   \
-                const int row = wm * WM + mi * 32 + frow;                                                       \
-                a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                   \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + af[mi][kk]); \
             _Pragma("unroll")                                                                                   \
-            for (int ni = 0; ni < NI; ++ni) {                                                                   \
-                const int row = wn * 64 + ni * 32 + frow;                                                       \
-                b[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + row * CV_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); \
-            }                                                                                                   \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + bf[ni][kk]); \
             _Pragma("unroll")                                                                                   \
             for (int mi = 0; mi < MI; ++mi)                                                                     \
                 _Pragma("unroll")                                                                               \
@@ -217,52 +224,65 @@ conv_igemm_kernel(ConvP p) {
         }                                                                                                       \
     }
 
-    if (PF == 1) {
+    if (PF == 1 && !dbuf) {
         CV_LOAD_TILE(p);
         CV_STORE_TILE(0, p);
         __syncthreads();
         for (int kt = 0; kt < p.KT; ++kt) {
-            const int buf = dbuf ? (kt & 1) : 0;
             const bool more = kt + 1 < p.KT;
             if (more) CV_LOAD_TILE(p);                          // global loads in flight during the MFMAs
-            CV_MFMA_STEP(buf);
+            CV_MFMA_STEP(0);
             if (more) {
-                if (!dbuf) __syncthreads();                      // single stage: everyone is done reading before the overwrite
-                CV_STORE_TILE(dbuf ? (buf ^ 1) : 0, p);
+                __syncthreads();                                // single stage: everyone is done reading before the overwrite
+                CV_STORE_TILE(0, p);
             }
             __syncthreads();
         }
+    } else if (PF == 1) {
+        CV_LOAD_TILE(p);
+        CV_STORE_TILE(0, p);
+        __syncthreads();
+        for (int kt = 0; kt < p.KT; kt += 2) {                  // two K-steps per trip: stages 0 and 1 are literals
+            if (kt + 1 < p.KT) CV_LOAD_TILE(p);
+            CV_MFMA_STEP(0);
+            if (kt + 1 >= p.KT) break;
+            CV_STORE_TILE(1, p);
+            __syncthreads();
+            if (kt + 2 < p.KT) CV_LOAD_TILE(p);
+            CV_MFMA_STEP(1);
+            if (kt + 2 < p.KT) CV_STORE_TILE(0, p);
+            __syncthreads();
+        }
     } else {
-        // tiles kt+1 (set q) and kt+2 (set p) are in flight while tile kt is multiplied; a set is re-issued as soon
-        // as it has been written to LDS, i.e. two K-steps before it is needed again
+        // PF = 2 (two stages): tiles kt+1 (set q) and kt+2 (set p) are in flight while tile kt is multiplied; a set is
+        // re-issued as soon as it has been written to LDS, i.e. two K-steps before it is needed again
         CV_LOAD_TILE(p);                                        // tile 0
         if (p.KT > 1) CV_LOAD_TILE(q);                          // tile 1
         CV_STORE_TILE(0, p);
         if (p.KT > 2) CV_LOAD_TILE(p);                          // tile 2
         __syncthreads();
-        const int odd_buf = dbuf ? 1 : 0;
         for (int kt = 0; kt < p.KT; kt += 2) {
             CV_MFMA_STEP(0);                                    // tile kt
             if (kt + 1 < p.KT) {
-                if (!dbuf) __syncthreads();
-                CV_STORE_TILE(odd_buf, q);                      // tile kt + 1
+                CV_STORE_TILE(1, q);                            // tile kt + 1
                 if (kt + 3 < p.KT) CV_LOAD_TILE(q);             // tile kt + 3
             }
             __syncthreads();
             if (kt + 1 >= p.KT) break;
-            CV_MFMA_STEP(odd_buf);                              // tile kt + 1
+            CV_MFMA_STEP(1);                                    // tile kt + 1
             if (kt + 2 < p.KT) {
-                if (!dbuf) __syncthreads();
                 CV_STORE_TILE(0, p);                            // tile kt + 2
                 if (kt + 4 < p.KT) CV_LOAD_TILE(p);             // tile kt + 4
             }
             __syncthreads();
         }
     }
+    __syncthreads();                                            // (the single/double-stage loops may leave through `break`)
 #undef CV_MFMA_STEP
 #undef CV_LOAD_TILE
 #undef CV_STORE_TILE
 #undef CV_ST
+#undef CV_BL
 
     // ---- epilogue: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free now) -> 16-B row stores
     constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row (padding: rows r, r+4 on disjoint banks)
@@ -360,7 +380,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     const long long M = (long long)N * Ho * Wo;
-    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);   // 32-bit byte offsets into x
     ConvP p;
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
     p.stats = stats;
@@ -387,14 +407,15 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
     const int pf = force_pf ? force_pf : (p.KT >= pf_kt ? 2 : 1);
     const int bn = wide ? 128 : 64;
     const int stage = CV_BM * (bn * 2 + 64) + 2048;                 // epilogue staging + column partials
-    const int loop = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
-    const int lds = loop > stage ? loop : stage;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
+    if (pf == 2) p.nbuf = 2;                                        // the two-tile prefetch is written for two LDS stages
+    const int loop2 = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
+    const int lds2 = loop2 > stage ? loop2 : stage;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
     (void)once;
-#define CV_LAUNCH(BN_, PF_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, PF_>), dim3(p.nblocks), dim3(DIR_TPB), lds, s, p)
-    if (wide) { if (pf == 2) CV_LAUNCH(128, 2); else CV_LAUNCH(128, 1); }
-    else      { if (pf == 2) CV_LAUNCH(64, 2);  else CV_LAUNCH(64, 1); }
+#define CV_LAUNCH(BN_, PF_, NB_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, PF_, NB_>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p)
+    if (wide) { if (pf == 2) CV_LAUNCH(128, 2, 2); else if (p.nbuf == 2) CV_LAUNCH(128, 1, 2); else CV_LAUNCH(128, 1, 1); }
+    else      { if (pf == 2) CV_LAUNCH(64, 2, 2);  else if (p.nbuf == 2) CV_LAUNCH(64, 1, 2);  else CV_LAUNCH(64, 1, 1); }
 #undef CV_LAUNCH
     DIR_LAUNCH_CHECK();
     return DIR_OK;
