@@ -16,6 +16,7 @@
 // Split-K: K is cut into `splits` contiguous ranges (one workgroup each, per tile and tap); partial tiles go to
 // a float32 workspace [split][Cout][R*S][Cin] and are summed in split order by a second kernel: deterministic,
 // no atomics, no zero-fill pass.
+#include <cstdlib>
 #include "dir_common.h"
 
 namespace {
@@ -297,7 +298,14 @@ WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
     pl.tiles_m = Cout / pl.tm; pl.tiles_n = Cin / pl.tn;
     pl.ksteps_total = (int)((M + WG_BK - 1) / WG_BK);
     const int tiles = pl.tiles_m * pl.tiles_n * RS;
-    int splits = (1024 + tiles - 1) / tiles;                     // aim at ~1024 workgroups (2 per CU, 2 rounds)
+    // Split-K so that the grid fills the chip a whole number of times: `slots` workgroups are resident at once (2 per CU
+    // for the 128x128 tile, 3 otherwise: registers / LDS), and a grid slightly above a multiple of that costs a whole
+    // extra round. One round measured best (4.99 -> 4.40 ms per ResNet-50 step at batch 256), unless that leaves fewer than
+    // 4 K ranges per tile (512-channel 3x3 layers): then two (DIR_WGRAD_ROUNDS overrides).
+    static const int force_rounds = []() { const char* e = getenv("DIR_WGRAD_ROUNDS"); return e ? atoi(e) : 0; }();
+    const int slots = 256 * ((pl.tm == 128 && pl.tn == 128) ? 2 : 3);
+    const int rounds = force_rounds ? force_rounds : (slots / tiles >= 4 ? 1 : 2);
+    int splits = rounds * slots / tiles;
     int max_splits = pl.ksteps_total / 4; if (max_splits < 1) max_splits = 1;      // >= 4 K-steps per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
