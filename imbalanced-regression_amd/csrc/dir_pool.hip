@@ -118,3 +118,69 @@ extern "C" int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Global average pool of the final [N, HW, C] bf16 map -> [N, C] float32 (resnet.py:85,136: AvgPool2d(7) on the 7x7
+// map) and its backward. The result goes straight into the float32 FDS / linear / loss tail, so the mean is formed
+// and kept in float32 (the library pool rounds it to bf16 first and its backward runs at 0.4 TB/s).
+namespace {
+__global__ void __launch_bounds__(DIR_TPB)
+avgpool_fwd_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int c8 = C / 8;
+    const int i = blockIdx.x * DIR_TPB + threadIdx.x;                  // (n, 8-channel group)
+    if (i >= N * c8) return;
+    const int n = i / c8, g = i - n * c8;
+    const uint16_t* p = x + ((size_t)n * HW) * C + g * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < HW; ++k) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)k * C);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(w[q] << 16); acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
+    }
+    const float inv = 1.0f / (float)HW;
+    float* o = y + (size_t)n * C + g * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+}
+
+__global__ void __launch_bounds__(DIR_TPB)
+avgpool_bwd_kernel(const float* __restrict__ dy, uint16_t* __restrict__ dx, int N, int HW, int C) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const int c8 = C / 8;
+    const size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x;       // (n, pixel, 8-channel group)
+    if (i >= (size_t)N * HW * c8) return;
+    const int g = (int)(i % c8);
+    const int n = (int)(i / ((size_t)HW * c8));
+    const float inv = 1.0f / (float)HW;
+    const float* s = dy + (size_t)n * C + g * 8;
+    const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+    const float v[8] = {a.x * inv, a.y * inv, a.z * inv, a.w * inv, b.x * inv, b.y * inv, b.z * inv, b.w * inv};
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x2_t t = {v[2 * q], v[2 * q + 1]}; w[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t)); }
+    *reinterpret_cast<uint4*>(dx + i * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+}  // namespace
+
+extern "C" int dir_avgpool_fwd(const void* x, float* y, int N, int HW, int C, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || N <= 0 || HW <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y), DIR_EINVAL);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(dir_cdiv((long long)N * (C / 8), DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream),
+                       static_cast<const uint16_t*>(x), y, N, HW, C);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_avgpool_bwd(const float* dy, void* dx, int N, int HW, int C, dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !dx || N <= 0 || HW <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(dx), DIR_EINVAL);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(dir_cdiv((long long)N * HW * (C / 8), DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream),
+                       dy, static_cast<uint16_t*>(dx), N, HW, C);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+

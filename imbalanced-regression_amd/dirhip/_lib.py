@@ -61,6 +61,8 @@ SIGNATURES = {
                                c_int, c_void_p, c_size_t, c_void_p]),
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dir_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dir_fds_bin_edges": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dir_fds_fill_empty_buckets": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_fds_prepare_scale_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),

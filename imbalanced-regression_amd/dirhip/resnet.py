@@ -23,7 +23,7 @@ import torch.nn as nn
 from .bn import BatchCounters, bn_act
 from .conv import conv_bn_input, supported as _igemm_ok
 from .fds import FDS
-from .pool import maxpool3x3s2
+from .pool import global_avgpool_flat, maxpool3x3s2
 
 print = logging.info
 
@@ -132,8 +132,7 @@ class ResNet(nn.Module):
         """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
         x = maxpool3x3s2(bn_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        x = self.avgpool(x)
-        return x.view(x.size(0), -1)
+        return global_avgpool_flat(x, self.avgpool)
 
     def _batch_counters(self):
         bc = getattr(self, "_dir_counters", None)

@@ -269,6 +269,11 @@ int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W
  * contain an input pixel (no atomics).  x [N,H,W,C], y/argmax [N,Ho,Wo,C], Ho = (H-1)/2+1;  C % 8 == 0. */
 int dir_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);
 int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int N, int H, int W, int C, dir_stream_t stream);
+/* Global average pool of the last feature map (imdb-wiki-dir/resnet.py:85,136-137: AvgPool2d(7) on the 7x7 map +
+ * view): x [N, HW, C] bf16 -> y [N, C] float32 (mean kept in float32 for the FDS / linear / loss tail), and its
+ * backward dx [N, HW, C] bf16 = dy / HW.  C % 8 == 0. */
+int dir_avgpool_fwd(const void* x, float* y, int N, int HW, int C, dir_stream_t stream);
+int dir_avgpool_bwd(const float* dy, void* dx, int N, int HW, int C, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * STS-B-DIR FDS variant (sts-b-dir/fds.py, sts-b-dir/util.py:63-73) — SURVEY.md §8f-2.  Same scatter / finalize /

@@ -125,3 +125,25 @@ def test_maxpool3x3s2_matches_torch():
         assert torch.equal(y.float(), yr)                                  # max of bf16 values is exact
         # ties (many exact zeros after ReLU) must route the gradient like torch: first maximum in scan order
         assert_close(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-2, atol_scale=1e-2, msg=str(shape))
+
+
+def test_global_avgpool_matches_fp32_reference():
+    from dirhip.pool import global_avgpool_flat
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for shape in ((8, 2048, 7, 7), (3, 64, 7, 7)):
+        x = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        pool = nn.AvgPool2d(7, stride=1)
+        y = global_avgpool_flat(x, pool)
+        assert y.dtype == torch.float32 and y.shape == (shape[0], shape[1])
+        dy = torch.randn(y.shape, device="cuda", generator=g)
+        y.backward(dy)
+        xr = x.detach().float().requires_grad_(True)
+        yr = pool(xr).view(shape[0], -1)
+        yr.backward(dy)
+        assert_close(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-6, atol_scale=1e-6, msg="mean")
+        assert x.grad.dtype == torch.bfloat16
+        assert torch.equal(x.grad, xr.grad.to(torch.bfloat16))              # dy / 49 rounded once to bf16
+    # a window that is not the whole map keeps using the module
+    x = torch.randn(2, 16, 9, 9, device="cuda").to(torch.bfloat16)
+    assert global_avgpool_flat(x, nn.AvgPool2d(7, stride=1)).shape == (2, 16 * 9)
