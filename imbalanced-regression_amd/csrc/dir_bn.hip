@@ -225,16 +225,22 @@ bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __r
 }
 
 // ---- forward: y = [relu]( x * a + b [+ residual] ) ---------------------------------------------------------
-template <typename T, bool RES, bool RELU>
+// RES: 0 = no residual, 1 = residual tensor added as is, 2 = residual is itself the INPUT of a BatchNorm whose
+// normalisation (rcoef) is applied on the fly (projection shortcut: relu(bn3(x) + bn_d(r)), resnet.py:63-68, without
+// materialising bn_d(r))
+template <typename T, int RES, bool RELU>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t M, int C, BnGeom g,
-                const float* __restrict__ coef) {
+                const float* __restrict__ coef, const float* __restrict__ rcoef) {
     constexpr int VEC = Vec<T>::N;
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
     const int c = blockIdx.y * g.ct + tg * VEC;
-    float a[VEC], b[VEC];
+    float a[VEC], b[VEC], a2[VEC], b2[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; b[j] = coef[C + c + j]; }
+    for (int j = 0; j < VEC; ++j) {
+        a[j] = coef[c + j]; b[j] = coef[C + c + j];
+        a2[j] = RES == 2 ? rcoef[c + j] : 1.0f; b2[j] = RES == 2 ? rcoef[C + c + j] : 0.0f;
+    }
     const int64_t stride = (int64_t)gridDim.x * g.rpi;
     // Mirrored row order (physical row = M-1-row): the statistics pass swept the tensor front to back, so its
     // tail is what L2 / the 256 MiB Infinity Cache still hold — re-read that first.
@@ -251,7 +257,8 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float o = v[u][j] * a[j] + b[j];
-                if (RES) o += r[u][j];
+                if (RES == 1) o += r[u][j];
+                if (RES == 2) o += r[u][j] * a2[j] + b2[j];
                 if (RELU) o = o > 0.0f ? o : 0.0f;
                 v[u][j] = o;
             }
@@ -265,7 +272,8 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float o = v[j] * a[j] + b[j];
-            if (RES) o += r[j];
+            if (RES == 1) o += r[j];
+            if (RES == 2) o += r[j] * a2[j] + b2[j];
             if (RELU) o = o > 0.0f ? o : 0.0f;
             v[j] = o;
         }
@@ -431,53 +439,78 @@ bool bn_shape_ok(int dtype, int64_t M, int C) {
     return C <= max_ct ? (DIR_TPB % (C / vec) == 0) : (C % max_ct == 0);
 }
 
+// statistics (own pass, or the partial list of the producing convolution's epilogue) -> save_mean / save_rstd,
+// running statistics and the apply coefficients coef[2][C]
+template <typename T>
+int prepare_impl(const void* x_, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
+                 float* running_var, double momentum, double eps, float* save_mean, float* save_rstd, float* coef,
+                 void* ws, size_t ws_bytes, hipStream_t s, const float* ext_partial, int ext_rows) {
+    constexpr int VEC = Vec<T>::N;
+    const T* x = static_cast<const T*>(x_);
+    BnGeom g = bn_geom<VEC>(M, C);
+    BnWs w = bn_ws<VEC>(ws, M, C);
+    DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
+    if (!coef) coef = w.coef;
+    const float* part = w.partial;
+    int prow = g.rblocks;
+    if (ext_partial) { part = ext_partial; prow = ext_rows; }       // statistics came out of the conv epilogue
+    else {
+        hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
+        DIR_LAUNCH_CHECK();
+    }
+    int splits = prow / 64;                                        // >= 64 rows per fold workgroup
+    if (splits > 32) splits = 32;
+    if (splits > g.rblocks / 2) splits = g.rblocks / 2;            // folded doubles live in the (unused) partial area
+    if (ext_partial && splits >= 4) {
+        const int rps = dir_cdiv(prow, splits);
+        splits = dir_cdiv(prow, rps);
+        double* folded = reinterpret_cast<double*>(w.partial);
+        hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3(dir_cdiv(C, 8), splits), dim3(DIR_TPB), 0, s, part, prow, C, rps, folded);
+        DIR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((bn_finalize_train_kernel<8, double>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, folded, splits, M, C,
+                           gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, coef);
+    } else {
+        hipLaunchKernelGGL((bn_finalize_train_kernel<8, float>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C,
+                           gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, coef);
+    }
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+template <typename T>
+int apply_impl(const void* x_, const void* res_, const float* rcoef, void* y_, int64_t M, int C, const float* coef, int relu,
+               hipStream_t s) {
+    constexpr int VEC = Vec<T>::N;
+    const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
+    BnGeom g = bn_geom<VEC>(M, C);
+    const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
+    if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    else if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
 template <typename T>
 int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const float* gamma, const float* beta,
              float* running_mean, float* running_var, double momentum, double eps, int relu, bool training,
              float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, hipStream_t s,
              const float* ext_partial = nullptr, int ext_rows = 0) {
     constexpr int VEC = Vec<T>::N;
-    const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
-    BnGeom g = bn_geom<VEC>(M, C);
     BnWs w = bn_ws<VEC>(ws, M, C);
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
-    const int cblocks = dir_cdiv(C, DIR_TPB);
     if (training) {
-        const float* part = w.partial;
-        int prow = g.rblocks;
-        if (ext_partial) { part = ext_partial; prow = ext_rows; }       // statistics came out of the conv epilogue
-        else {
-            hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, x, M, C, g, w.partial);
-            DIR_LAUNCH_CHECK();
-        }
-        // (a 2-channel x 128-slice variant for the conv epilogue's long partial lists measured slower — 16.6 vs 11.5 us:
-        //  its 8-byte loads touch 32 cache lines per wave instruction)
-        int splits = prow / 64;                                        // >= 64 rows per fold workgroup
-        if (splits > 32) splits = 32;
-        if (splits > g.rblocks / 2) splits = g.rblocks / 2;            // folded doubles live in the (unused) partial area
-        if (ext_partial && splits >= 4) {
-            const int rps = dir_cdiv(prow, splits);
-            splits = dir_cdiv(prow, rps);
-            double* folded = reinterpret_cast<double*>(w.partial);
-            hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3(dir_cdiv(C, 8), splits), dim3(DIR_TPB), 0, s, part, prow, C, rps, folded);
-            DIR_LAUNCH_CHECK();
-            hipLaunchKernelGGL((bn_finalize_train_kernel<8, double>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, folded, splits, M, C,
-                               gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
-        } else {
-            hipLaunchKernelGGL((bn_finalize_train_kernel<8, float>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, s, part, prow, M, C,
-                               gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, w.coef);
-        }
+        const int rc = prepare_impl<T>(x_, M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
+                                       w.coef, ws, ws_bytes, s, ext_partial, ext_rows);
+        if (rc != DIR_OK) return rc;
     } else {
-        hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cblocks), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
+        hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
+        DIR_LAUNCH_CHECK();
     }
-    DIR_LAUNCH_CHECK();
-    const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
-    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
-    else hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), grid, blk, 0, s, x, res, y, M, C, g, w.coef);
-    DIR_LAUNCH_CHECK();
-    return DIR_OK;
+    return apply_impl<T>(x_, res_, nullptr, y_, M, C, w.coef, relu, s);
 }
 
 template <typename T>
@@ -581,3 +614,30 @@ extern "C" int dir_bn_bwd(const void* dout, const void* x, const void* out, void
     return bwd_impl<float>(dout, x, out, dx, dres, M, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, relu,
                            workspace, workspace_bytes, dir_s(stream));
 }
+
+extern "C" int dir_bn_prepare_train(const void* x, int dtype, int64_t M, int C, const float* partial, int partial_rows,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    double momentum, double eps, float* save_mean, float* save_rstd, float* coef,
+                                    void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !gamma || !beta || !save_mean || !save_rstd || !coef || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF((running_mean == nullptr) != (running_var == nullptr) || (partial && partial_rows <= 0), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return prepare_impl<bf16_t>(x, M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, coef,
+                                    workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
+    return prepare_impl<float>(x, M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, coef,
+                               workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
+}
+
+extern "C" int dir_bn_apply(const void* x, const void* residual, const float* residual_coef, void* y, int dtype, int64_t M,
+                            int C, const float* coef, int relu, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !coef || (residual_coef && !residual), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    if (dtype == DIR_BF16) return apply_impl<bf16_t>(x, residual, residual_coef, y, M, C, coef, relu, dir_s(stream));
+    return apply_impl<float>(x, residual, residual_coef, y, M, C, coef, relu, dir_s(stream));
+}
+

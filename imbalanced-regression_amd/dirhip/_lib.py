@@ -47,6 +47,9 @@ SIGNATURES = {
                                 c_void_p, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_bn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_prepare_train": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
     "dir_conv_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_conv_prep_weights_batched": (c_int, [c_void_p, c_int, c_void_p]),

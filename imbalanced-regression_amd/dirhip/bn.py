@@ -100,6 +100,97 @@ class _BNActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
+class _BNJoinFn(torch.autograd.Function):
+    """``relu(bn(x) + bn_r(r))`` — the projection-shortcut join — as one node: both BatchNorms are prepared, one apply
+    pass normalises both inputs and adds them (``dir_bn_prepare_train`` x2 + ``dir_bn_apply``); the backward is the two
+    BatchNorm backwards on the shared (masked) gradient. Training mode, channels_last only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, momentum, eps, partial, r, gamma_r, beta_r, rm_r, rv_r, momentum_r, eps_r,
+                partial_r, relu, deferred):
+        x, r = _nhwc(x), _nhwc(r)
+        if r.dtype != x.dtype:
+            r = r.to(x.dtype)
+        n, c, h, w = x.shape
+        m = n * h * w
+        code = _DT[x.dtype]
+        dev = x.device
+        stream = L.stream_ptr(dev)
+        y = torch.empty_like(x)
+        ws = _ws(code, m, c, dev)
+        f32 = torch.float32
+        mean, rstd, mean_r, rstd_r = (torch.empty(c, dtype=f32, device=dev) for _ in range(4))
+        coef, coef_r = torch.empty(2, c, dtype=f32, device=dev), torch.empty(2, c, dtype=f32, device=dev)
+        for (t, part, g_, b_, rm_, rv_, mom, ep, mu, rs, cf) in ((x, partial, gamma, beta, rm, rv, momentum, eps, mean, rstd, coef),
+                                                                 (r, partial_r, gamma_r, beta_r, rm_r, rv_r, momentum_r, eps_r,
+                                                                  mean_r, rstd_r, coef_r)):
+            L.check(L.lib().dir_bn_prepare_train(L.ptr(t), code, m, c, L.ptr(part), 0 if part is None else part.shape[0],
+                                                 L.ptr(g_), L.ptr(b_), L.ptr(rm_), L.ptr(rv_), float(mom), float(ep), L.ptr(mu),
+                                                 L.ptr(rs), L.ptr(cf), L.ptr(ws), ws.numel(), stream), "dir_bn_prepare_train")
+        L.check(L.lib().dir_bn_apply(L.ptr(x), L.ptr(r), L.ptr(coef_r), L.ptr(y), code, m, c, L.ptr(coef), int(relu), stream),
+                "dir_bn_apply")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, r, gamma_r, beta_r, mean_r, rstd_r, y if relu else None)
+        ctx.relu = bool(relu)
+        ctx.deferred = deferred
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, beta, mean, rstd, r, gamma_r, beta_r, mean_r, rstd_r, y = ctx.saved_tensors
+        dout = _nhwc(dout)
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        n, c, h, w = x.shape
+        m = n * h * w
+        code = _DT[x.dtype]
+        dev = x.device
+        stream = L.stream_ptr(dev)
+        f32 = torch.float32
+        dx, dr = torch.empty_like(x), torch.empty_like(r)
+        dgamma, dbeta, dgamma_r, dbeta_r = (torch.empty(c, dtype=f32, device=dev) for _ in range(4))
+        ws = _ws(code, m, c, dev)
+        link = ctx.deferred
+        if not ctx.relu or (link is not None and link[0]):
+            g = dout                                         # no ReLU, or its backward was applied by the consumer (bn_act doc)
+            L.check(L.lib().dir_bn_bwd(L.ptr(g), L.ptr(x), None, L.ptr(dx), None, code, m, c, L.ptr(gamma), L.ptr(beta),
+                                       L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(ws), ws.numel(), stream),
+                    "dir_bn_bwd")
+        else:
+            g = torch.empty_like(x)                          # masked gradient = the shortcut branch's gradient
+            L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(g), code, m, c, L.ptr(gamma), L.ptr(beta),
+                                       L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), 1, L.ptr(ws), ws.numel(), stream),
+                    "dir_bn_bwd")
+        L.check(L.lib().dir_bn_bwd(L.ptr(g), L.ptr(r), None, L.ptr(dr), None, code, m, c, L.ptr(gamma_r), L.ptr(beta_r),
+                                   L.ptr(mean_r), L.ptr(rstd_r), L.ptr(dgamma_r), L.ptr(dbeta_r), 0, L.ptr(ws), ws.numel(), stream),
+                "dir_bn_bwd")
+        return (dx, dgamma, dbeta, None, None, None, None, None, dr, dgamma_r, dbeta_r, None, None, None, None, None, None, None)
+
+
+def _count_batch(bn):
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        counter = getattr(bn, "_dir_step_counter", None)
+        if counter is not None:
+            counter.pending += 1                 # one fused increment for all layers (BatchCounters.flush)
+        else:
+            bn.num_batches_tracked.add_(1)
+
+
+def bn_join(x, bn, partial, r, bn_r, partial_r, relu=True, defer_relu_grad=False):
+    """``relu(bn(x) + bn_r(r))`` in training mode with both normalisations applied in one pass (see ``_BNJoinFn``).
+    ``partial`` / ``partial_r``: conv-epilogue statistics of x / r or None."""
+    assert bn.training and bn_r.training and bn.momentum is not None and bn_r.momentum is not None
+    _count_batch(bn)
+    _count_batch(bn_r)
+    deferred = [False] if (defer_relu_grad and relu and torch.is_grad_enabled()) else None
+    trs, trs_r = bn.track_running_stats, bn_r.track_running_stats
+    y = _BNJoinFn.apply(x, bn.weight, bn.bias, bn.running_mean if trs else None, bn.running_var if trs else None, bn.momentum,
+                        bn.eps, partial, r, bn_r.weight, bn_r.bias, bn_r.running_mean if trs_r else None,
+                        bn_r.running_var if trs_r else None, bn_r.momentum, bn_r.eps, partial_r, relu, deferred)
+    if deferred is not None:
+        y._dir_relu_flag = deferred
+    return y
+
+
 def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False):
     """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``. ``partial`` =
     the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only).

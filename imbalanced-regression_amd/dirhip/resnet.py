@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .bn import BatchCounters, bn_act
+from .bn import BatchCounters, bn_act, bn_join
 from .conv import conv_bn_input, supported as _igemm_ok
 from .fds import FDS
 from .pool import global_avgpool_flat, maxpool3x3s2
@@ -69,6 +69,16 @@ class Bottleneck(nn.Module):
             y, partial, xin = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True,
                                             relu_flag=getattr(x, "_dir_relu_flag", None))
             y = bn_act(y, self.bn1, relu=True, partial=partial)
+            if self.downsample is not None and self.bn3.training and self.downsample[1].training and "bn_join" not in _DISABLED \
+                    and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) \
+                    and _igemm_ok(self.downsample[0].in_channels, self.downsample[0].out_channels):
+                # projection block: relu(bn3(conv3(.)) + bn_d(conv_d(x))) with both normalisations in ONE apply pass
+                # (bn_d's output is never materialised)
+                r, partial_r = conv_bn_input(xin, self.downsample[0], want_stats=True)
+                y = _conv_bn(y, self.conv2, self.bn2, relu=True)
+                y3, partial3 = conv_bn_input(y, self.conv3, want_stats=True)
+                return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True,
+                               defer_relu_grad="relu_defer" not in _DISABLED)
             shortcut = xin if self.downsample is None else _conv_bn(xin, self.downsample[0], self.downsample[1], relu=False)
         else:
             shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)

@@ -217,6 +217,18 @@ int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void*
                int64_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                const float* save_rstd, float* dgamma, float* dbeta, int relu, void* workspace,
                size_t workspace_bytes, dir_stream_t stream);
+/* The two halves of dir_bn_fwd_train[_partials] on their own, for the projection-shortcut join
+ * relu(bn3(x) + bn_d(r)) of imdb-wiki-dir/resnet.py:63-68 (bn_d = downsample[1]): both BatchNorms are prepared
+ * (statistics -> save_mean/save_rstd, running statistics, coef[2][C] = scale/shift), then ONE apply pass normalises
+ * x and r and adds them, so bn_d(r) is never written or re-read.
+ *   dir_bn_prepare_train: partial == NULL -> statistics pass over x; else partial [partial_rows][2][C] from dir_conv_fwd.
+ *   dir_bn_apply: y = [relu](x * coef[0] + coef[1] [+ residual | + residual * residual_coef[0] + residual_coef[1]]). */
+int dir_bn_prepare_train(const void* x, int dtype, int64_t M, int C, const float* partial, int partial_rows,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, double momentum,
+                         double eps, float* save_mean, float* save_rstd, float* coef, void* workspace,
+                         size_t workspace_bytes, dir_stream_t stream);
+int dir_bn_apply(const void* x, const void* residual, const float* residual_coef, void* y, int dtype, int64_t M, int C,
+                 const float* coef, int relu, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  convolution as MFMA implicit GEMM, NHWC bf16, fp32 accumulation.  Replaces nn.Conv2d (bias=False) of

@@ -147,3 +147,41 @@ def test_global_avgpool_matches_fp32_reference():
     # a window that is not the whole map keeps using the module
     x = torch.randn(2, 16, 9, 9, device="cuda").to(torch.bfloat16)
     assert global_avgpool_flat(x, nn.AvgPool2d(7, stride=1)).shape == (2, 16 * 9)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_bn_join_matches_two_separate_batchnorms(deferred):
+    """relu(bn(x) + bn_r(r)) in one apply pass vs BatchNorm(r) materialised first (fp32 torch reference for both)."""
+    from dirhip.bn import bn_join
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shape = (8, 256, 14, 14)
+    x0 = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r0 = (torch.randn(shape, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bn, bn_r = nn.BatchNorm2d(256).cuda(), nn.BatchNorm2d(256).cuda()
+    ref, ref_r = nn.BatchNorm2d(256).cuda(), nn.BatchNorm2d(256).cuda()
+    with torch.no_grad():
+        for m_, s_ in ((bn, 1), (bn_r, 2)):
+            m_.weight.copy_(torch.rand(256, device="cuda", generator=g) + 0.5)
+            m_.bias.copy_(torch.randn(256, device="cuda", generator=g) * 0.1)
+        ref.load_state_dict(bn.state_dict()); ref_r.load_state_dict(bn_r.state_dict())
+    x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    y = bn_join(x, bn, None, r, bn_r, None, relu=True, defer_relu_grad=deferred)
+    xf, rf = x0.float().requires_grad_(True), r0.float().requires_grad_(True)
+    yf = torch.relu(ref(xf) + ref_r(rf))
+    if deferred:                       # the consumer promises the masked gradient
+        y._dir_relu_flag[0] = True
+        y.backward(torch.where(y > 0, dy, torch.zeros_like(dy)))
+    else:
+        y.backward(dy)
+    yf.backward(dy.float())
+    assert_close(y.float().detach().cpu().numpy(), yf.detach().cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="y")
+    assert_close(x.grad.float().cpu().numpy(), xf.grad.cpu().numpy(), rtol=2e-2, atol_scale=8e-3, msg="dx")
+    assert_close(r.grad.float().cpu().numpy(), rf.grad.cpu().numpy(), rtol=2e-2, atol_scale=8e-3, msg="dr")
+    for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad), (bn_r.weight.grad, ref_r.weight.grad),
+                 (bn_r.bias.grad, ref_r.bias.grad)):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-2, atol_scale=1e-2, msg="param grad")
+    for a, b in ((bn.running_mean, ref.running_mean), (bn.running_var, ref.running_var), (bn_r.running_mean, ref_r.running_mean),
+                 (bn_r.running_var, ref_r.running_var)):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running stats")
+    assert int(bn.num_batches_tracked) == 1 and int(bn_r.num_batches_tracked) == 1

@@ -192,10 +192,19 @@ def test_projection_bottleneck_fused_shortcut_gradient_matches_unfused(stride):
 
     o1, gx1, gp1 = run(True)
     o2, gx2, gp2 = run(False)
-    assert torch.equal(o1, o2)
-    assert_close(gx1.cpu().numpy(), gx2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
+    # the block's own forward also joins bn3 and the projection's BatchNorm in one pass (no bf16 rounding of the
+    # normalised shortcut in between): equal up to that rounding
+    # (outputs within a bf16 ulp of zero flip their ReLU mask, so gradients are compared in the L2 sense)
+    assert_close(o1.cpu().numpy(), o2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="out")
+
+    def l2(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    # ~0.2 % of the outputs lie within the skipped rounding step of zero; each flip moves one gradient term by O(1):
+    # expected relative L2 distance sqrt(0.002) ~ 4 %
+    assert l2(gx1, gx2) < 8e-2, l2(gx1, gx2)
     for a, b in zip(gp1, gp2):
-        assert torch.equal(a, b)
+        assert l2(a, b) < 8e-2, l2(a, b)
 
 
 def test_batched_weight_preparation_matches_single_layer_path():
