@@ -641,3 +641,13 @@ extern "C" int dir_bn_apply(const void* x, const void* residual, const float* re
     return apply_impl<float>(x, residual, residual_coef, y, M, C, coef, relu, dir_s(stream));
 }
 
+// (internal, used by dir_pool.hip's fused stem tail) partial [rows][2][C] of (sum g, sum g*x) -> dgamma, dbeta, coef[3][C]
+extern "C" int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
+                                   const float* save_rstd, float* dgamma, float* dbeta, float* coef, dir_stream_t stream) {
+    DIR_RETURN_IF(!partial || rows <= 0 || M <= 0 || C <= 0 || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !coef, DIR_EINVAL);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, dir_s(stream), partial, rows, M, C, gamma,
+                       save_mean, save_rstd, dgamma, dbeta, coef);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+

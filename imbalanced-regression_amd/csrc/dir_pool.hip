@@ -120,6 +120,208 @@ extern "C" int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stem tail: relu(bn1(x)) -> MaxPool2d(3, 2, 1) (resnet.py:80-82,129-131) in one pass over the BatchNorm INPUT: the
+// normalised 112x112 map (411 MB at batch 256) is never written or re-read. Forward: per window the maximum of
+// x * a + b (float), clipped at 0, rounded to bf16 once; argmax byte 0..8 = window position, 9 = clipped by the ReLU (no
+// gradient). Backward: the BatchNorm reductions run over the POOLED gradient (sum g = sum of unclipped dy,
+// sum g x = sum dy * x[argmax]); the apply pass is the gather-style pool backward with dx = a g + p x + q folded in.
+namespace {
+constexpr int SP_BLOCKS = 1024;                                   // workgroups (= partial rows) of the reduction pass
+
+__global__ void __launch_bounds__(DIR_TPB)
+bn_relu_maxpool_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ coef, uint16_t* __restrict__ y,
+                           uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const int cg = C / 8;
+    const long long total = (long long)N * Ho * Wo * cg;
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < total; i += (long long)gridDim.x * DIR_TPB) {
+        const int g = (int)(i % cg); long long p = i / cg;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+        float a[8], b[8], best[8]; uint32_t bi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = coef[g * 8 + j]; b[j] = coef[C + g * 8 + j]; best[j] = -INFINITY; bi[j] = 9; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + hi) * W + wi) * C + g * 8);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float f0 = pl_bf2f(w4[q] & 0xffffu) * a[2 * q] + b[2 * q];
+                    const float f1 = pl_bf2f(w4[q] >> 16) * a[2 * q + 1] + b[2 * q + 1];
+                    if (f0 > best[2 * q]) { best[2 * q] = f0; bi[2 * q] = r * 3 + s; }                   // first max wins
+                    if (f1 > best[2 * q + 1]) { best[2 * q + 1] = f1; bi[2 * q + 1] = r * 3 + s; }
+                }
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v0 = best[2 * q], v1 = best[2 * q + 1];
+            if (!(v0 > 0.0f)) { v0 = 0.0f; bi[2 * q] = 9; }                                               // ReLU
+            if (!(v1 > 0.0f)) { v1 = 0.0f; bi[2 * q + 1] = 9; }
+            const f32x2_t t = {v0, v1};
+            o[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t));
+        }
+        const size_t oo = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+        *reinterpret_cast<uint4*>(y + oo) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint2*>(idx + oo) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                         bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+    }
+}
+
+// partial[block][2][C]: sums of g and g * x over the windows this workgroup visits (fixed order: deterministic)
+__global__ void __launch_bounds__(DIR_TPB)
+bn_relu_maxpool_bwd_partial_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, const uint16_t* __restrict__ x,
+                                   float* __restrict__ partial, int N, int H, int W, int C, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];    // [2][DIR_TPB][8]
+    const int cg = C / 8;                                         // DIR_TPB % cg == 0: a thread keeps its channel group
+    const long long total = (long long)N * Ho * Wo * cg;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.0f; s1[j] = 0.0f; }
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < total; i += (long long)gridDim.x * DIR_TPB) {
+        const int g = (int)(i % cg); long long p = i / cg;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+        const size_t oo = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+        const uint2 iv = *reinterpret_cast<const uint2*>(idx + oo);
+        const uint4 gv = *reinterpret_cast<const uint4*>(dy + oo);
+        const uint32_t g4[4] = {gv.x, gv.y, gv.z, gv.w};
+        const size_t xb = (((size_t)n * H + (2 * ho - 1)) * W + (2 * wo - 1)) * C + g * 8;   // window origin (may lie outside: never dereferenced there)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t k = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+            if (k < 9u) {
+                const float gj = pl_bf2f((j & 1) ? (g4[j >> 1] >> 16) : (g4[j >> 1] & 0xffffu));
+                const uint32_t r = k / 3u, s2 = k - 3u * r;
+                const float xv = pl_bf2f(x[xb + ((size_t)r * W + s2) * C + j]);
+                s0[j] += gj; s1[j] += gj * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[(0 * DIR_TPB + threadIdx.x) * 8 + j] = s0[j]; sh[(1 * DIR_TPB + threadIdx.x) * 8 + j] = s1[j]; }
+    __syncthreads();
+    const int lanes = DIR_TPB / cg;                               // threads per channel group
+    if ((int)threadIdx.x < 2 * C) {
+        const int which = threadIdx.x / C, c = threadIdx.x - which * C, g = c / 8, j = c - g * 8;
+        float sum = 0.0f;
+        for (int l = 0; l < lanes; ++l) sum += sh[(which * DIR_TPB + l * cg + g) * 8 + j];
+        partial[((size_t)blockIdx.x * 2 + which) * C + c] = sum;
+    }
+}
+
+// coef[3][C] = (a, p, q) of the BatchNorm backward: dx = a g + p x + q with g gathered from the pooled gradient
+__global__ void __launch_bounds__(DIR_TPB)
+bn_relu_maxpool_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, const uint16_t* __restrict__ x,
+                                 const float* __restrict__ coef, uint16_t* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const int cg = C / 8;
+    const long long total = (long long)N * H * W * cg;
+    for (long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x; i < total; i += (long long)gridDim.x * DIR_TPB) {
+        const int g = (int)(i % cg); long long p = i / cg;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); const int n = (int)(p / H);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                             // the (<= 2x2) windows containing (h, w)
+            const int ho = (h + 1) / 2 - a;
+            const int r = h - (2 * ho - 1);
+            if (ho < 0 || ho >= Ho || r < 0 || r > 2) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int wo = (w + 1) / 2 - b;
+                const int s = w - (2 * wo - 1);
+                if (wo < 0 || wo >= Wo || s < 0 || s > 2) continue;
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + g * 8;
+                const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+                const uint4 gv = *reinterpret_cast<const uint4*>(dy + o);
+                const uint32_t me = (uint32_t)(r * 3 + s);
+                const uint32_t g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t k = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t hbits = (j & 1) ? (g4[j >> 1] >> 16) : (g4[j >> 1] & 0xffffu);
+                    if (k == me) acc[j] += pl_bf2f(hbits);
+                }
+            }
+        }
+        const size_t xo = (((size_t)n * H + h) * W + w) * C + g * 8;
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + xo);
+        const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+        uint32_t o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = g * 8 + 2 * q;
+            const float v0 = coef[c0] * acc[2 * q] + coef[C + c0] * pl_bf2f(x4[q] & 0xffffu) + coef[2 * C + c0];
+            const float v1 = coef[c0 + 1] * acc[2 * q + 1] + coef[C + c0 + 1] * pl_bf2f(x4[q] >> 16) + coef[2 * C + c0 + 1];
+            const f32x2_t t = {v0, v1};
+            o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t));
+        }
+        *reinterpret_cast<uint4*>(dx + xo) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+}  // namespace
+
+extern "C" int dir_bn_relu_maxpool_fwd(const void* x, const float* coef, void* y, void* argmax, int N, int H, int W, int C,
+                                       dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !coef || !y || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const uint16_t*>(x), coef,
+                       static_cast<uint16_t*>(y), static_cast<uint8_t*>(argmax), N, H, W, C, Ho, Wo);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" size_t dir_bn_relu_maxpool_bwd_workspace(int C) {
+    if (C <= 0 || C % 8 != 0) return 0;
+    return dir_align_up(sizeof(float) * (size_t)SP_BLOCKS * 2 * C, 256) + dir_align_up(sizeof(float) * 3 * (size_t)C, 256);
+}
+
+// defined in dir_bn.hip: partial [rows][2][C] -> dgamma, dbeta, coef[3][C]
+extern "C" int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
+                                   const float* save_rstd, float* dgamma, float* dbeta, float* coef, dir_stream_t stream);
+
+extern "C" int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, void* dx, int N, int H, int W, int C,
+                                       const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
+                                       float* dbeta, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !argmax || !x || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(C % 8 != 0 || DIR_TPB % (C / 8) != 0 || 2 * C > DIR_TPB, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(workspace_bytes < dir_bn_relu_maxpool_bwd_workspace(C), DIR_EWORKSPACE);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    float* partial = static_cast<float*>(workspace);
+    float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + dir_align_up(sizeof(float) * (size_t)SP_BLOCKS * 2 * C, 256));
+    hipStream_t s = dir_s(stream);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_partial_kernel, dim3(SP_BLOCKS), dim3(DIR_TPB), 2 * DIR_TPB * 8 * sizeof(float), s,
+                       static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), partial,
+                       N, H, W, C, Ho, Wo);
+    DIR_LAUNCH_CHECK();
+    const int rc = dir_bn_bwd_finalize(partial, SP_BLOCKS, (int64_t)N * H * W, C, gamma, save_mean, save_rstd, dgamma, dbeta, coef, stream);
+    if (rc != DIR_OK) return rc;
+    const long long total = (long long)N * H * W * (C / 8);
+    int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid), dim3(DIR_TPB), 0, s, static_cast<const uint16_t*>(dy),
+                       static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), coef, static_cast<uint16_t*>(dx), N, H, W, C, Ho, Wo);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Global average pool of the final [N, HW, C] bf16 map -> [N, C] float32 (resnet.py:85,136: AvgPool2d(7) on the 7x7
 // map) and its backward. The result goes straight into the float32 FDS / linear / loss tail, so the mean is formed
 // and kept in float32 (the library pool rounds it to bf16 first and its backward runs at 0.4 TB/s).

@@ -64,6 +64,12 @@ SIGNATURES = {
                                c_int, c_void_p, c_size_t, c_void_p]),
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_bn_relu_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_bn_relu_maxpool_bwd_workspace": (c_size_t, [c_int]),
+    "dir_bn_relu_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "dir_avgpool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dir_avgpool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dir_fds_bin_edges": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -72,3 +72,65 @@ def global_avgpool_flat(x, module):
     y = module(x)
     return y.view(y.size(0), -1)
 
+
+class _BnReluMaxPoolFn(torch.autograd.Function):
+    """Stem tail ``maxpool(relu(bn(x)))`` (training mode) on the BatchNorm input: statistics pass + finalize
+    (``dir_bn_prepare_train``), then one fused normalise / ReLU / 3x3-s2 max pass; backward = BatchNorm reductions over
+    the pooled gradient + one fused pool-backward / BatchNorm-apply pass (``dir_bn_relu_maxpool_*``)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+        n, c, h, w = x.shape
+        m = n * h * w
+        dev = x.device
+        stream = L.stream_ptr(dev)
+        f32 = torch.float32
+        mean, rstd = torch.empty(c, dtype=f32, device=dev), torch.empty(c, dtype=f32, device=dev)
+        coef = torch.empty(2, c, dtype=f32, device=dev)
+        nbytes = L.lib().dir_bn_workspace(L.DIR_BF16, m, c)
+        if nbytes == 0:
+            raise L.DirHipError(f"dir_bn: unsupported shape M={m} C={c}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(L.lib().dir_bn_prepare_train(L.ptr(x), L.DIR_BF16, m, c, None, 0, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                             L.ptr(running_var), float(momentum), float(eps), L.ptr(mean), L.ptr(rstd), L.ptr(coef),
+                                             L.ptr(ws), ws.numel(), stream), "dir_bn_prepare_train")
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, c, ho, wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
+        L.check(L.lib().dir_bn_relu_maxpool_fwd(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), n, h, w, c, stream),
+                "dir_bn_relu_maxpool_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, idx = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.lib().dir_bn_relu_maxpool_bwd_workspace(c), dtype=torch.uint8, device=dev)
+        L.check(L.lib().dir_bn_relu_maxpool_bwd(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
+                                                L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
+                "dir_bn_relu_maxpool_bwd")
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def bn_relu_maxpool(x, bn, pool):
+    """``pool(relu(bn(x)))`` for the stem (``bn`` = nn.BatchNorm2d, ``pool`` = nn.MaxPool2d(3, 2, 1)). Fused when
+    training on a bf16 CUDA map; otherwise the fused BatchNorm node followed by the pool."""
+    from .bn import _count_batch, bn_act
+    c = x.shape[1]
+    ok = (x.is_cuda and x.dtype == torch.bfloat16 and bn.training and bn.track_running_stats and bn.momentum is not None
+          and c % 8 == 0 and c <= 128 and 256 % (c // 8) == 0 and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2))
+          and pool.padding in (1, (1, 1)) and not pool.ceil_mode)
+    if not ok:
+        return maxpool3x3s2(bn_act(x, bn, relu=True), pool)
+    _count_batch(bn)
+    return _BnReluMaxPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+

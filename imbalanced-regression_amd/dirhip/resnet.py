@@ -23,7 +23,7 @@ import torch.nn as nn
 from .bn import BatchCounters, bn_act, bn_join
 from .conv import conv_bn_input, supported as _igemm_ok
 from .fds import FDS
-from .pool import global_avgpool_flat, maxpool3x3s2
+from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
 
 print = logging.info
 
@@ -140,7 +140,10 @@ class ResNet(nn.Module):
 
     def features(self, x):
         """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
-        x = maxpool3x3s2(bn_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
+        if "stem_tail" in _DISABLED:
+            x = maxpool3x3s2(bn_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
+        else:
+            x = bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return global_avgpool_flat(x, self.avgpool)
 

@@ -286,6 +286,22 @@ int dir_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int N, in
  * backward dx [N, HW, C] bf16 = dy / HW.  C % 8 == 0. */
 int dir_avgpool_fwd(const void* x, float* y, int N, int HW, int C, dir_stream_t stream);
 int dir_avgpool_bwd(const float* dy, void* dx, int N, int HW, int C, dir_stream_t stream);
+/* Stem tail relu(bn1(x)) -> MaxPool2d(3, 2, 1) (imdb-wiki-dir/resnet.py:80-82,129-131) in one pass over the BatchNorm
+ * INPUT x [N, H, W, C] bf16: the normalised map is never materialised.
+ *   fwd: coef [2][C] from dir_bn_prepare_train; y [N, Ho, Wo, C] bf16; argmax [N, Ho, Wo, C] u8 (0..8 window position,
+ *        9 = clipped by the ReLU).
+ *   bwd: dy = gradient of y; dx = gradient of x (BatchNorm backward included: dgamma, dbeta out).
+ *        workspace >= dir_bn_relu_maxpool_bwd_workspace(C) bytes.  C % 8 == 0, C <= 128. */
+int dir_bn_relu_maxpool_fwd(const void* x, const float* coef, void* y, void* argmax, int N, int H, int W, int C,
+                            dir_stream_t stream);
+size_t dir_bn_relu_maxpool_bwd_workspace(int C);
+int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, void* dx, int N, int H, int W, int C,
+                            const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* Second third of dir_bn_bwd on its own: partial [rows][2][C] f32 of (sum g, sum g*x) -> dgamma, dbeta and
+ * coef [3][C] = (a, p, q) with dx = a g + p x + q. */
+int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
+                        const float* save_rstd, float* dgamma, float* dbeta, float* coef, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * STS-B-DIR FDS variant (sts-b-dir/fds.py, sts-b-dir/util.py:63-73) — SURVEY.md §8f-2.  Same scatter / finalize /

@@ -185,3 +185,34 @@ def test_bn_join_matches_two_separate_batchnorms(deferred):
                  (bn_r.running_var, ref_r.running_var)):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running stats")
     assert int(bn.num_batches_tracked) == 1 and int(bn_r.num_batches_tracked) == 1
+
+
+def test_stem_bn_relu_maxpool_matches_unfused():
+    """Fused stem tail vs torch fp32 BatchNorm -> ReLU -> MaxPool2d(3, 2, 1)."""
+    from dirhip.pool import bn_relu_maxpool
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for shape in ((4, 64, 32, 32), (3, 64, 9, 7)):
+        x0 = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        bn, ref = nn.BatchNorm2d(64).cuda(), nn.BatchNorm2d(64).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(64, device="cuda", generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(64, device="cuda", generator=g) * 0.3)
+            ref.load_state_dict(bn.state_dict())
+        pool = nn.MaxPool2d(3, 2, 1)
+        x = x0.clone().requires_grad_(True)
+        y = bn_relu_maxpool(x, bn, pool)
+        xr = x0.float().requires_grad_(True)
+        yr = pool(torch.relu(ref(xr)))
+        dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        yr.backward(dy.float())
+        assert_close(y.float().detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="y")
+
+        def l2(a, b):
+            return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+        # argmax ties / near-ties may route single gradient terms differently: compare in the L2 sense
+        assert l2(x.grad.float(), xr.grad) < 3e-2, l2(x.grad.float(), xr.grad)
+        assert l2(bn.weight.grad, ref.weight.grad) < 1e-2 and l2(bn.bias.grad, ref.bias.grad) < 1e-2
+        assert_close(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running mean")
+        assert_close(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running var")
+        assert int(bn.num_batches_tracked) == 1
