@@ -30,6 +30,8 @@ struct ConvP {
     const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
     const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
     const uint16_t* mask;     // optional [M][Cout] bf16: result zeroed where !(mask > 0) (fused ReLU backward)
+    const uint16_t* addend2;  // optional COMPACT addend [N][Ho/2][Wo/2][Cout] bf16, added at the even (ho, wo) only: the data
+                              // gradient of a 1x1 stride-2 convolution of the same input, never scattered to full size
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int M, KT, cpk, ntn, nblocks;
     int simple;               // 1x1, stride 1, pad 0: row m of the GEMM is row m of x (no index arithmetic at all)
@@ -331,6 +333,24 @@ conv_igemm_kernel(ConvP p) {
                                           __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
                 c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
             }
+            if (p.addend2) {                                    // rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :]
+                const int m = m0 + srow + i * RPI;
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+                if (!((ho | wo) & 1)) {
+                    const size_t co = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8;
+                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend2 + co);
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2)
+                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+            }
             if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
                 const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
                 const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
@@ -357,6 +377,9 @@ extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
 extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
                                   float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   dir_stream_t stream);
+static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
+                       float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                       dir_stream_t stream);
 
 extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
                                 int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
@@ -371,7 +394,20 @@ extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats,
 extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
                                   float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   dir_stream_t stream) {
+    return conv_launch(x, w, addend, nullptr, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+}
+
+extern "C" int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2,
+                                   const void* relu_mask, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                   int pad, dir_stream_t stream) {
+    return conv_launch(x, w, addend, addend_s2, relu_mask, y, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, stream);
+}
+
+static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
+                       float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                       dir_stream_t stream) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
+    DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || stats), DIR_EINVAL);
     DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
     DIR_RETURN_IF(relu_mask && (!dir_aligned16(relu_mask) || stats), DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
@@ -379,6 +415,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(addend_s2 && ((Ho | Wo) & 1), DIR_EUNSUPPORTED);
     const long long M = (long long)N * Ho * Wo;
     DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);   // 32-bit byte offsets into x
     ConvP p;
@@ -386,6 +423,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
     p.stats = stats;
     p.addend = static_cast<const uint16_t*>(addend);
     p.mask = static_cast<const uint16_t*>(relu_mask);
+    p.addend2 = static_cast<const uint16_t*>(addend_s2);
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;

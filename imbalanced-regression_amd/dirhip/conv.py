@@ -13,7 +13,7 @@ def supported(cin, cout):
     return cin % 64 == 0 and cout % 64 == 0
 
 
-def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None):
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None):
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -39,6 +39,14 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         assert relu_mask.shape == y.shape and relu_mask.dtype == torch.bfloat16 and not want_stats
         if not relu_mask.is_contiguous(memory_format=torch.channels_last):
             relu_mask = relu_mask.contiguous(memory_format=torch.channels_last)
+    if addend_s2 is not None:
+        # compact data gradient of a stride-2 1x1 convolution of the same input: added at the even pixels only
+        assert addend_s2.shape == (n, cout, ho // 2, wo // 2) and addend_s2.dtype == torch.bfloat16 and not want_stats and stride == 1
+        if not addend_s2.is_contiguous(memory_format=torch.channels_last):
+            addend_s2 = addend_s2.contiguous(memory_format=torch.channels_last)
+        L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
+                                            cin, cout, r, s, padding, L.stream_ptr(x.device)), "dir_conv_dgrad_join")
+        return y
     L.check(L.lib().dir_conv_fwd_fused(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(relu_mask), L.ptr(y), L.ptr(stats), n, h, wd,
                                        cin, cout, r, s, stride, padding, L.stream_ptr(x.device)), "dir_conv_fwd")
     return (y, stats) if want_stats else y
@@ -104,7 +112,7 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         need_dx = ctx.needs_input_grad[0]
         dx = None
-        if need_dx and w16_rot is not None:
+        if need_dx and w16_rot is not None and ctx.stride == 1:
             # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
             # in/out-transposed weights and padding R-1-pad
             dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias,
@@ -119,6 +127,53 @@ class _ConvFn(torch.autograd.Function):
         if dalias is not None:                                                   # strided layer: eager accumulation
             dx = dalias if dx is None else dx + dalias
         return dx, dw, None, None, None, None, None, None, None
+
+
+class _ProjectionPairFn(torch.autograd.Function):
+    """The two 1x1 convolutions that read a projection block's input (``conv1`` stride 1 and ``downsample[0]`` stride
+    1 or 2, resnet.py:57-68) as ONE node, so that their data gradients meet inside one kernel: the downsample conv's
+    data gradient is computed in its compact form (a plain 1x1 GEMM on its dY) and added — at the even pixels when the
+    stride is 2 — inside conv1's data-gradient store loop (``dir_conv_dgrad_join``), together with the ReLU backward
+    of the previous block's output. No strided transposed convolution, no zero fill, no gradient-add kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input):
+        ctx.set_materialize_grads(False)
+        ctx.stride_d, ctx.relu_input = stride_d, relu_input
+        if want_stats:
+            y1, s1 = conv2d_igemm(x, w1_16, 1, 0, want_stats=True)
+            yd, sd = conv2d_igemm(x, wd_16, stride_d, 0, want_stats=True)
+            ctx.mark_non_differentiable(s1, sd)
+        else:
+            y1, s1 = conv2d_igemm(x, w1_16, 1, 0), None
+            yd, sd = conv2d_igemm(x, wd_16, stride_d, 0), None
+        ctx.save_for_backward(x, w1_rot, wd_rot)
+        return y1, s1, yd, sd
+
+    @staticmethod
+    def backward(ctx, dy1, _ds1, dyd, _dsd):
+        x, w1_rot, wd_rot = ctx.saved_tensors
+
+        def prep(t):
+            if t is None:
+                return None
+            if t.dtype != torch.bfloat16:
+                t = t.to(torch.bfloat16)
+            return t.contiguous(memory_format=torch.channels_last)
+        dy1, dyd = prep(dy1), prep(dyd)
+        mask = x if ctx.relu_input else None
+        compact = conv2d_igemm(dyd, wd_rot, 1, 0) if dyd is not None else None
+        if dy1 is None:
+            raise L.DirHipError("projection pair: conv1's output received no gradient")
+        if compact is None:
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, relu_mask=mask)
+        elif ctx.stride_d == 1:
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask)
+        else:
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask)
+        dw1 = conv2d_wgrad(dy1, x, 1, 1, 0)
+        dwd = conv2d_wgrad(dyd, x, 1, ctx.stride_d, 0) if dyd is not None else None
+        return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -146,7 +201,7 @@ class _PreparedWeights:
         self.shape = (cout, r * s, cin)
         self.w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
         self.w16_rot = None
-        if conv.stride[0] == 1 and supported(cout, cin):
+        if (conv.stride[0] == 1 or (r == 1 and s == 1)) and supported(cout, cin):
             # [Cin][R][S][Cout], taps rotated by 180 degrees: the weight of the data-gradient convolution
             self.w16_rot = torch.empty((cin, cout, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
         self.key = None
@@ -230,7 +285,7 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     aliasing = bool(alias_input and grad_mode and x.requires_grad)
     # relu_flag (a one-element list made by bn_act(defer_relu_grad=True) for the tensor x): claimed only when EVERY use
     # of x goes through this node (alias mode) and the data gradient is our own kernel, which can mask on store
-    relu_input = bool(relu_flag is not None and aliasing and w16_rot is not None and not relu_flag[0])
+    relu_input = bool(relu_flag is not None and aliasing and w16_rot is not None and conv.stride[0] == 1 and not relu_flag[0])
     if relu_input:
         relu_flag[0] = True
     y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if grad_mode else None, conv.stride[0], conv.padding[0],
@@ -238,3 +293,29 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     if alias_input:
         return y, stats, (alias if alias is not None else x)
     return y, stats
+
+
+def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
+    """``conv1(x)`` and ``conv_d(x)`` (both 1x1, bias-free, padding 0; ``conv1`` stride 1) as one node — see
+    ``_ProjectionPairFn``. Returns ``(y1, stats1, yd, statsd)``. ``relu_flag``: as in ``conv_bn_input`` (x is only
+    used here, so the flag can always be claimed when gradients flow)."""
+    w1_16, w1_rot = _prepared(conv1)
+    wd_16, wd_rot = _prepared(conv_d)
+    assert w1_rot is not None and wd_rot is not None
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+        relu_flag = None
+    grad_mode = torch.is_grad_enabled()
+    relu_input = bool(relu_flag is not None and grad_mode and x.requires_grad and not relu_flag[0])
+    if relu_input:
+        relu_flag[0] = True
+    return _ProjectionPairFn.apply(x, conv1.weight, w1_16, w1_rot, conv_d.weight, wd_16, wd_rot, conv_d.stride[0], want_stats,
+                                   relu_input)
+
+
+def projection_pair_ok(conv1, conv_d):
+    def one(c, strides):
+        return (c.kernel_size == (1, 1) and c.padding == (0, 0) and c.stride[0] in strides and c.stride[0] == c.stride[1]
+                and c.bias is None and c.groups == 1 and supported(c.in_channels, c.out_channels))
+    return one(conv1, (1,)) and one(conv_d, (1, 2))
+

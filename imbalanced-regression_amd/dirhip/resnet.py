@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .bn import BatchCounters, bn_act, bn_join
-from .conv import conv_bn_input, supported as _igemm_ok
+from .conv import conv_bn_input, projection_pair, projection_pair_ok, supported as _igemm_ok
 from .fds import FDS
 from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
 
@@ -60,6 +60,19 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16 and self.downsample is not None and "proj_pair" not in _DISABLED and self.bn3.training \
+                and self.downsample[1].training and projection_pair_ok(self.conv1, self.downsample[0]) \
+                and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) and (x.shape[2] | x.shape[3]) % 2 == 0:
+            # projection block: conv1 and the downsample conv are one node (their data gradients and the previous
+            # block's ReLU backward meet inside one kernel, the stride-2 gradient in compact form), and
+            # relu(bn3(conv3(.)) + bn_d(conv_d(x))) is one join with both normalisations in ONE apply pass
+            y, partial, r, partial_r = projection_pair(x, self.conv1, self.downsample[0], want_stats=True,
+                                                       relu_flag=getattr(x, "_dir_relu_flag", None))
+            y = bn_act(y, self.bn1, relu=True, partial=partial)
+            y = _conv_bn(y, self.conv2, self.bn2, relu=True)
+            y3, partial3 = conv_bn_input(y, self.conv3, want_stats=True)
+            return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True,
+                           defer_relu_grad="relu_defer" not in _DISABLED)
         if x.dtype == torch.bfloat16 and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels) and \
                 (self.downsample is None or "proj_alias" not in _DISABLED):
             # conv1's node also hands back the block input, and the shortcut branch (identity or projection) reads THAT:

@@ -264,6 +264,13 @@ int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, 
  * one of them is given. */
 int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y, float* stats,
                        int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
+/* Data gradient at a projection block's input (imdb-wiki-dir/resnet.py:57-68: x feeds conv1 AND the stride-2 1x1
+ * downsample conv): y = relu'(relu_mask) * bf16(bf16(conv(x, w)) + addend + up2(addend_s2)), stride 1.  addend_s2 is the
+ * COMPACT data gradient of the downsample conv, [N, Ho/2, Wo/2, Cout] bf16 (= its dY times its transposed weight, a
+ * plain 1x1 stride-1 launch of this kernel): it is added at the even (ho, wo) only, so the 4x larger zero-filled
+ * scatter a strided transposed convolution would write (and this launch re-read) never exists.  Ho, Wo even. */
+int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
+                        void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the

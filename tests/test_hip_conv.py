@@ -274,3 +274,22 @@ def test_deferred_relu_backward_is_bit_identical():
     assert torch.equal(gx1, gx2)
     for a, b in zip(gp1, gp2):
         assert torch.equal(a, b)
+
+
+def test_dgrad_join_adds_compact_stride2_gradient_at_even_pixels():
+    """dir_conv_dgrad_join: conv + up2(compact) must equal the dense result plus the zero-upsampled compact tensor, bitwise."""
+    from dirhip.conv import conv2d_igemm
+    g = torch.Generator(device="cuda").manual_seed(31)
+    n, cin, cout, h = 3, 64, 128, 12
+    x = torch.randn(n, cin, h, h, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, device="cuda", generator=g) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    compact = torch.randn(n, cout, h // 2, h // 2, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    mask = torch.randn(n, cout, h, h, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dense = conv2d_igemm(x, w, 1, 0)
+    up = torch.zeros_like(dense)
+    up[:, :, ::2, ::2] = compact
+    ref = (dense.float() + up.float()).to(torch.bfloat16)
+    got = conv2d_igemm(x, w, 1, 0, addend_s2=compact)
+    assert torch.equal(got, ref)
+    got_m = conv2d_igemm(x, w, 1, 0, addend_s2=compact, relu_mask=mask)
+    assert torch.equal(got_m, torch.where(mask.float() > 0, ref, torch.zeros_like(ref)))
