@@ -319,3 +319,61 @@ def projection_pair_ok(conv1, conv_d):
                 and c.bias is None and c.groups == 1 and supported(c.in_channels, c.out_channels))
     return one(conv1, (1,)) and one(conv_d, (1, 2))
 
+
+class _StemConvFn(torch.autograd.Function):
+    """7x7 / stride-2 stem convolution on a bf16 channels_last image: forward = ``dir_stem_conv_fwd`` (+ BatchNorm partial
+    statistics), weight gradient = library kernel for now; the image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x16, weight, wpack, want_stats):
+        ctx.set_materialize_grads(False)
+        n, c, h, w = x16.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, 64, ho, wo), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
+        stats = None
+        if want_stats:
+            stats = torch.empty((L.lib().dir_stem_conv_stats_rows(n, h), 2, 64), dtype=torch.float32, device=x16.device)
+            ctx.mark_non_differentiable(stats)
+        L.check(L.lib().dir_stem_conv_fwd(L.ptr(x16), L.ptr(wpack), L.ptr(y), L.ptr(stats), n, h, w, L.stream_ptr(x16.device)),
+                "dir_stem_conv_fwd")
+        ctx.save_for_backward(x16, weight)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x16, weight = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dw = torch.ops.aten.convolution_backward(dy, x16, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                 [False, True, False])[1]
+        return None, dw.to(weight.dtype), None, None
+
+
+def stem_conv_ok(x, conv):
+    return (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and conv.in_channels == 3 and conv.out_channels == 64
+            and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.bias is None
+            and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[3] % 8 == 0 and x.shape[3] <= 256
+            and conv.weight.dtype == torch.float32)
+
+
+def stem_conv(x, conv, want_stats):
+    """``conv(x)`` for the 7x7/2 stem in bf16 (what autocast computes) with the hand-written kernel; returns ``(y, partial
+    statistics or None)``. ``x``: float32 or bf16 image batch, any memory format."""
+    w = conv.weight
+    key = _weight_key(w)
+    cache = getattr(conv, "_dir_wpack", None)
+    if cache is None or cache[0] != key or cache[1].device != w.device:
+        wd = w.detach()
+        if not wd.is_contiguous(memory_format=torch.channels_last):
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        wpack = cache[1] if cache is not None and cache[1].device == w.device else torch.empty((64, 176), dtype=torch.bfloat16, device=w.device)
+        L.check(L.lib().dir_stem_conv_prep_weights(L.ptr(wd), L.ptr(wpack), L.stream_ptr(w.device)), "dir_stem_conv_prep_weights")
+        object.__setattr__(conv, "_dir_wpack", (key, wpack))
+    else:
+        wpack = cache[1]
+    x16 = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    x16 = x16.contiguous(memory_format=torch.channels_last)
+    return _StemConvFn.apply(x16, w, wpack, want_stats)
+

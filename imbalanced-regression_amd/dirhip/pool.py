@@ -79,7 +79,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
     the pooled gradient + one fused pool-backward / BatchNorm-apply pass (``dir_bn_relu_maxpool_*``)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, partial=None):
         x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
         n, c, h, w = x.shape
         m = n * h * w
@@ -92,7 +92,8 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         if nbytes == 0:
             raise L.DirHipError(f"dir_bn: unsupported shape M={m} C={c}")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        L.check(L.lib().dir_bn_prepare_train(L.ptr(x), L.DIR_BF16, m, c, None, 0, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+        L.check(L.lib().dir_bn_prepare_train(L.ptr(x), L.DIR_BF16, m, c, L.ptr(partial), 0 if partial is None else partial.shape[0],
+                                             L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
                                              L.ptr(running_var), float(momentum), float(eps), L.ptr(mean), L.ptr(rstd), L.ptr(coef),
                                              L.ptr(ws), ws.numel(), stream), "dir_bn_prepare_train")
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -118,19 +119,20 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         L.check(L.lib().dir_bn_relu_maxpool_bwd(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
                                                 L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
                 "dir_bn_relu_maxpool_bwd")
-        return dx, dgamma, dbeta, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def bn_relu_maxpool(x, bn, pool):
+def bn_relu_maxpool(x, bn, pool, partial=None):
     """``pool(relu(bn(x)))`` for the stem (``bn`` = nn.BatchNorm2d, ``pool`` = nn.MaxPool2d(3, 2, 1)). Fused when
-    training on a bf16 CUDA map; otherwise the fused BatchNorm node followed by the pool."""
+    training on a bf16 CUDA map; otherwise the fused BatchNorm node followed by the pool. ``partial``: statistics of x
+    from the producing convolution's epilogue (``conv.stem_conv``) or None."""
     from .bn import _count_batch, bn_act
     c = x.shape[1]
     ok = (x.is_cuda and x.dtype == torch.bfloat16 and bn.training and bn.track_running_stats and bn.momentum is not None
           and c % 8 == 0 and c <= 128 and 256 % (c // 8) == 0 and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2))
           and pool.padding in (1, (1, 1)) and not pool.ceil_mode)
     if not ok:
-        return maxpool3x3s2(bn_act(x, bn, relu=True), pool)
+        return maxpool3x3s2(bn_act(x, bn, relu=True, partial=partial), pool)
     _count_batch(bn)
-    return _BnReluMaxPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    return _BnReluMaxPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, partial)
 

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .bn import BatchCounters, bn_act, bn_join
-from .conv import conv_bn_input, projection_pair, projection_pair_ok, supported as _igemm_ok
+from .conv import conv_bn_input, projection_pair, projection_pair_ok, stem_conv, stem_conv_ok, supported as _igemm_ok
 from .fds import FDS
 from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
 
@@ -153,10 +153,16 @@ class ResNet(nn.Module):
 
     def features(self, x):
         """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
-        if "stem_tail" in _DISABLED:
-            x = maxpool3x3s2(bn_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
+        partial = None
+        if "stem_conv" not in _DISABLED and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
+                and stem_conv_ok(x, self.conv1):
+            x, partial = stem_conv(x, self.conv1, want_stats=self.bn1.training)   # hand-written MFMA stem, statistics in its epilogue
         else:
-            x = bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)
+            x = self.conv1(x)
+        if "stem_tail" in _DISABLED:
+            x = maxpool3x3s2(bn_act(x, self.bn1, relu=True, partial=partial), self.maxpool)
+        else:
+            x = bn_relu_maxpool(x, self.bn1, self.maxpool, partial=partial)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return global_avgpool_flat(x, self.avgpool)
 

@@ -271,6 +271,14 @@ int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const v
  * scatter a strided transposed convolution would write (and this launch re-read) never exists.  Ho, Wo even. */
 int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
                         void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, dir_stream_t stream);
+/* Stem convolution 7x7 / stride 2 / pad 3, 3 -> 64 channels (imdb-wiki-dir/resnet.py:79,129), MFMA without an im2col
+ * buffer.  x [N, H, W, 3] bf16 (channels_last image), wpack = dir_stem_conv_prep_weights(w) with w the float32 master
+ * weight [64][7][7][3] (= channels_last [64, 3, 7, 7]); y [N, Ho, Wo, 64] bf16; stats (may be NULL)
+ * [dir_stem_conv_stats_rows(N, H)][2][64] f32 partial sums / sums of squares of the rounded outputs for dir_bn_*.
+ * W % 8 == 0, Wo <= 128 (W <= 256). */
+size_t dir_stem_conv_stats_rows(int N, int H);
+int dir_stem_conv_prep_weights(const float* w, void* wpack /* [64][176] bf16 */, dir_stream_t stream);
+int dir_stem_conv_fwd(const void* x, const void* wpack, void* y, float* stats, int N, int H, int W, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the

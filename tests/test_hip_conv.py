@@ -293,3 +293,34 @@ def test_dgrad_join_adds_compact_stride2_gradient_at_even_pixels():
     assert torch.equal(got, ref)
     got_m = conv2d_igemm(x, w, 1, 0, addend_s2=compact, relu_mask=mask)
     assert torch.equal(got_m, torch.where(mask.float() > 0, ref, torch.zeros_like(ref)))
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 224, 224), (2, 3, 64, 40), (3, 3, 18, 8)])
+def test_stem_conv_matches_fp32_reference(shape):
+    """dir_stem_conv_fwd (7x7/2, 3 -> 64) vs F.conv2d on the bf16-rounded operands in fp32; statistics vs the stored output."""
+    import torch.nn as nn
+    from dirhip.conv import stem_conv, stem_conv_ok
+    torch.manual_seed(7)
+    conv = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(41)
+    x = torch.randn(shape, device="cuda", generator=g)
+    assert stem_conv_ok(x, conv)
+    y, stats = stem_conv(x, conv, want_stats=True)
+    ref = F.conv2d(x.to(torch.bfloat16).float(), conv.weight.detach().to(torch.bfloat16).float(), None, 2, 3)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert_close(y.float().detach().cpu().numpy(), ref.cpu().numpy(), rtol=4e-3, atol_scale=2e-3, msg="y")
+    yf = y.detach().double()
+    tot = stats.double().sum(0)
+    assert_close(tot[0].cpu().numpy(), yf.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sum")
+    assert_close(tot[1].cpu().numpy(), (yf * yf).sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sumsq")
+    # weight gradient flows (library kernel), and the packed weights follow an optimizer step
+    y.float().square().mean().backward()
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    F.conv2d(x.to(torch.bfloat16).float(), wr, None, 2, 3).square().mean().backward()
+    rel = ((conv.weight.grad - wr.grad).norm() / wr.grad.norm()).item()
+    assert rel < 3e-2, rel
+    opt = torch.optim.SGD(conv.parameters(), lr=1.0)
+    opt.step()
+    y2, _ = stem_conv(x, conv, want_stats=False)
+    ref2 = F.conv2d(x.to(torch.bfloat16).float(), conv.weight.detach().to(torch.bfloat16).float(), None, 2, 3)
+    assert_close(y2.float().detach().cpu().numpy(), ref2.cpu().numpy(), rtol=4e-3, atol_scale=2e-3, msg="y after step")
