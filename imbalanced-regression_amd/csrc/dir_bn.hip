@@ -10,6 +10,7 @@
 // thread owns 8 (bf16) / 4 (f32) consecutive channels = one 16-byte load per row and walks rows with a stride;
 // per-channel constants live in registers; partial sums go through LDS once per workgroup and through a small
 // [row-blocks][C] float buffer once per launch (no atomics -> bit-reproducible), combined in float64.
+#include <cstdlib>
 #include "dir_common.h"
 
 namespace {
@@ -31,7 +32,8 @@ BnGeom bn_geom(int64_t M, int C) {
     g.rpi = DIR_TPB / g.tpr;
     g.ctiles = C / g.ct;
     int64_t want = (M + (int64_t)g.rpi * 4 - 1) / ((int64_t)g.rpi * 4);   // >= 4 row iterations per workgroup
-    int64_t cap = 1024 / g.ctiles; if (cap < 1) cap = 1;   // <= 1024 workgroups, <= 1024/ctiles partial rows per channel
+    static const int cap_total = []() { const char* e = getenv("DIR_BN_CAP"); return e ? atoi(e) : 768; }();
+    int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768 workgroups = 3 per CU (measured: 256..4096 swept, DIR_BN_CAP), <= 768/ctiles partial rows per channel
     g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     return g;
 }
