@@ -6,17 +6,21 @@
 //   Y[m, co] = sum_{r,s,ci} X[n, ho*stride - pad + r, wo*stride - pad + s, ci] * Wt[co, r, s, ci],   m = (n, ho, wo)
 //
 // GEMM view: M = N*Ho*Wo rows, N = Cout columns, K = R*S*Cin with Cin % 64 == 0, so one 64-wide K-step never
-// straddles a filter tap and the A-operand loader is "row pointer + bounds predicate" (zero fill at the borders).
+// straddles a filter tap and the A-operand loader is "per-row byte offset + wave-uniform tap offset" into a raw buffer
+// load; taps outside the image are sent out of the buffer's range, where the hardware returns zeros.
 // Both operands are K-contiguous in memory (NHWC activations, [Cout][R][S][Cin] weights = torch channels_last), which
 // is exactly the 16-bytes-per-lane fragment of v_mfma_f32_32x32x16_bf16 — no transposes anywhere.
 //
 // Workgroup = 256 threads = 4 wavefronts (one per SIMD), tile 128 x BN x 64 (BN = 128 or 64):
-//   global -> registers (16 B per lane, next K-step prefetched while the current one is multiplied)
+//   global -> registers (buffer_load_dwordx4, 16 B per lane, next K-step(s) prefetched while the current one is multiplied)
 //   registers -> LDS, rows of 128 B, 16-B chunks XOR-swizzled with (row >> 1) & 7 so that both the 8-lane
 //   ds_write_b128 groups and the four 16-lane ds_read_b128 groups are bank-conflict free
 //   LDS -> MFMA fragments -> 32x32x16 bf16 MFMA, fp32 accumulators (2x2 or 1x2 tiles of 32x32 per wavefront)
-//   epilogue: bf16 rounding, optional per-channel (sum, sum of squares) partials of the rounded outputs for the
-//   following BatchNorm (no separate statistics pass over Y), LDS transpose staging, 16-B coalesced row stores.
+//   epilogue: v_cvt_pk_bf16_f32 + 16-bit LDS stores into a staging tile, optional per-channel (sum, sum of squares)
+//   partials of the rounded outputs for the following BatchNorm (no separate statistics pass over Y), 16-B coalesced
+//   row stores with optional fused "+ addend", "+ compact stride-2 addend" and ReLU-backward mask (data-gradient use).
+// All LDS offsets are computed once and pinned in registers, the LDS stage is a template literal: a K-step is 16 MFMAs,
+// 24 LDS and 8 buffer instructions and ~16 VALU instructions.
 // Workgroup ids are remapped so that the N-tiles of one M-tile run on the same XCD (A tile re-reads hit that L2).
 #include <cstdlib>
 #include "dir_common.h"

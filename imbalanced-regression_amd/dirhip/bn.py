@@ -1,6 +1,11 @@
 """Fused BatchNorm2d (+ residual add) (+ ReLU) for channels_last activations — one autograd node per BN layer,
-three HIP launches forward (statistics, finalize, apply) and three backward (reduce, finalize, apply) instead of
-MIOpen BatchNorm + separate add / ReLU / ReLU-backward kernels (``dir_bn_*`` in ``include/dir_hip.h``).
+two to three HIP launches forward (statistics — or none when the producing convolution's epilogue supplied them —,
+finalize, apply) and three backward (reduce, finalize, apply) instead of the library BatchNorm + separate add / ReLU /
+ReLU-backward kernels (``dir_bn_*`` in ``include/dir_hip.h``).
+
+Also here: ``bn_join`` — the projection-shortcut join ``relu(bn(x) + bn_r(r))`` with both normalisations applied in one
+pass — and the hand-over that lets the consumer of a ``relu(bn(x) + shortcut)`` output apply that ReLU's backward inside
+its own data-gradient kernel (``defer_relu_grad``).
 
 ``bn_act(x, bn, relu, residual)`` reads its parameters and running statistics from the ``nn.BatchNorm2d`` module
 ``bn`` that ``resnet.py`` registers (so state_dict keys and checkpoint compatibility are untouched) and implements

@@ -1,8 +1,12 @@
-"""MFMA implicit-GEMM convolution (``dir_conv_fwd``) — tensor-level wrapper.
+"""MFMA convolutions (``dir_conv_*``, ``dir_stem_conv_*``) — tensor-level wrappers and autograd nodes.
 
 ``conv2d_igemm(x, w, stride, padding, want_stats)``: x ``[N, Cin, H, W]`` and w ``[Cout, Cin, R, S]``, both bf16 and
 channels_last (so their memory is NHWC / ``[Cout][R][S][Cin]``); returns y (channels_last bf16) and, optionally,
-the per-tile BatchNorm partial statistics ``[rows][2][Cout]`` float32.
+the per-tile BatchNorm partial statistics ``[rows][2][Cout]`` float32. The same kernel computes stride-1 data
+gradients (rotated weights), with the gradient accumulation of a fan-out (``addend`` / ``addend_s2``) and a ReLU backward
+(``relu_mask``) fused into its store loop. ``conv2d_wgrad``: deterministic split-K weight gradient.
+``conv_bn_input`` / ``projection_pair`` / ``stem_conv``: the autograd nodes ``resnet.py`` is built from; the bf16 operands
+of all layers are re-made by one launch per optimizer step.
 """
 import torch
 
