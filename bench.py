@@ -364,7 +364,7 @@ def main():
         "value": images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own implicit-GEMM MFMA kernels fwd/dgrad/wgrad) + fused HIP BatchNorm nodes / fp32 FDS+loss tail, "
+        "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own MFMA kernels: stem, implicit-GEMM fwd/dgrad/wgrad) + fused HIP BatchNorm / join / pool nodes, fp32 FDS+loss tail, "
                                "batch=256 per MI355X, l1 loss, Adam 1e-3", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "epoch_len_steps": args.epoch_len, "epoch_tails_in_timed_region": n_tails, "parallelism": f"dp{world}",
                    "final_loss": loss_val},
