@@ -40,6 +40,8 @@ struct ConvP {
     int M, KT, cpk, ntn, nblocks;
     int simple;               // 1x1, stride 1, pad 0: row m of the GEMM is row m of x (no index arithmetic at all)
     float inv_wo, inv_ho;     // reciprocals for the (n, ho, wo) decode of the general case
+    int o2, o_a, o_b, OH, OW; // o2: output row (n, i, j) is stored at pixel (2 i + o_a, 2 j + o_b) of an [N][OH][OW][Cout] tensor
+                              // (one parity class of a stride-2 data gradient); else rows are stored densely
     int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
 };
 
@@ -327,6 +329,16 @@ conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
         if (full || m0 + srow + i * RPI < p.M) {
             uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+            if (p.o2) {                                         // parity class of a stride-2 data gradient: scattered rows
+                const int m = m0 + srow + i * RPI;
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+                const size_t orow = ((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b;
+                *reinterpret_cast<uint4*>(p.y + orow * p.Cout + n0 + sch * 8) = c;
+                continue;
+            }
             if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
                 const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
                 uint32_t cw[4] = {c.x, c.y, c.z, c.w};
@@ -384,6 +396,9 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                        float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        dir_stream_t stream);
+static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
+                          float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          int cls_a, int cls_b, int reserved, dir_stream_t stream);
 
 extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
                                 int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
@@ -407,9 +422,32 @@ extern "C" int dir_conv_dgrad_join(const void* x, const void* w, const void* add
     return conv_launch(x, w, addend, addend_s2, relu_mask, y, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, stream);
 }
 
+extern "C" int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                                 dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !wcls || !dx, DIR_EINVAL);
+    // classes (a, b) in the order (0,0) (0,1) (1,0) (1,1): 1, 2, 2, 4 filter taps, packed back to back as [Cx][taps][Cy]
+    static const int tap_base[4] = {0, 1, 3, 5};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const uint16_t* wc = static_cast<const uint16_t*>(wcls) + (size_t)tap_base[a * 2 + b] * Cx * Cy;
+            const int rc = conv_launch_ex(dy, wc, nullptr, nullptr, nullptr, dx, nullptr, N, Ho, Wo, Cy, Cx, 1 + a, 1 + b, 1, 0, a, b, 0, stream);
+            if (rc != DIR_OK) return rc;
+        }
+    return DIR_OK;
+}
+
 static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                        float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        dir_stream_t stream) {
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, 0, stream);
+}
+
+// cls_a >= 0: parity class (cls_a, cls_b) of a stride-2 data gradient: x = dY [N, H, W, Cin], kernel (1 + a) x (1 + b)
+// anchored top-left (zero beyond the bottom / right edge), output grid H x W stored at pixels (2 i + a, 2 j + b) of
+// y [N, 2 H, 2 W, Cout]
+static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
+                          float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          int cls_a, int cls_b, int /*reserved*/, dir_stream_t stream) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
     DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || stats), DIR_EINVAL);
     DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
@@ -417,7 +455,9 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
-    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const bool cls = cls_a >= 0;
+    DIR_RETURN_IF(cls && (stride != 1 || pad != 0 || addend || addend_s2 || relu_mask || stats), DIR_EINVAL);
+    const int Ho = cls ? H : (H + 2 * pad - R) / stride + 1, Wo = cls ? W : (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     DIR_RETURN_IF(addend_s2 && ((Ho | Wo) & 1), DIR_EUNSUPPORTED);
     const long long M = (long long)N * Ho * Wo;
@@ -432,6 +472,8 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
     p.inv_wo = 1.0f / (float)Wo; p.inv_ho = 1.0f / (float)Ho;
+    p.o2 = cls ? 1 : 0; p.o_a = cls ? cls_a : 0; p.o_b = cls ? cls_b : 0; p.OH = 2 * H; p.OW = 2 * W;
+    DIR_RETURN_IF(cls && (long long)N * 4 * H * W * Cout >= (1ll << 31), DIR_EUNSUPPORTED);
     const int mtiles = (int)((M + CV_BM - 1) / CV_BM);
     const bool wide = (Cout % 128 == 0);
     p.ntn = wide ? Cout / 128 : Cout / 64;
@@ -472,8 +514,22 @@ namespace {
 // One layer: w [Cout][RS][Cin] f32 -> w16 (same layout, bf16) and optionally w16_rot [Cin][RS][Cout] with the taps
 // reversed. Cin, Cout % 64 == 0: the (co, ci) transpose of each tap goes through a 64x64 LDS tile, so both the float
 // reads (256 B rows) and the two bf16 writes (128 B rows) are coalesced. Tiles are strided over gridDim.x.
+// rot_mode 0: w16_rot = [Cin][R][S][Cout] with the taps rotated by 180 degrees (stride-1 data gradient).
+// rot_mode 1 (3x3 only): w16_rot = the four parity-class weights of the STRIDE-2 data gradient, packed back to back:
+//   class (a, b) = (r != 1, s != 1) holds the (1 + a) x (1 + b) taps that reach output pixels (2 i + a, 2 j + b), as
+//   [Cin][(1 + a)(1 + b)][Cout] with tap (dr, ds) = (r == 0, s == 0) (dY row i + dr, column j + ds); class bases at
+//   0, 1, 3, 5 taps.
+__device__ __forceinline__ size_t conv_prep_rot_index(int rot_mode, int ci, int tap, int co, int RS, int Cin, int Cout) {
+    if (rot_mode == 0) return ((size_t)ci * RS + (RS - 1 - tap)) * Cout + co;
+    const int r = tap / 3, s = tap - 3 * r;
+    const int a = r != 1, b = s != 1, dr = r == 0, ds = s == 0;
+    const int taps = (1 + a) * (1 + b), t = dr * (1 + b) + ds;
+    const int base = a ? (b ? 5 : 3) : (b ? 1 : 0);
+    return (size_t)base * Cin * Cout + ((size_t)ci * taps + t) * Cout + co;
+}
+
 __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int Cout, int RS, int Cin,
-                                               uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot) {
+                                               uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot, int rot_mode) {
     __shared__ uint16_t tile[64][66];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;           // 4 rows of 64 per pass
     if ((Cout & 63) || (Cin & 63)) {                               // generic fallback (not used by ResNet-50's layers)
@@ -483,7 +539,7 @@ __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int 
             w16[i] = h;
             if (w16_rot) {
                 const int ci = (int)(i % Cin); const size_t t1 = i / Cin; const int tap = (int)(t1 % RS); const int co = (int)(t1 / RS);
-                w16_rot[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = h;
+                w16_rot[conv_prep_rot_index(rot_mode, ci, tap, co, RS, Cin, Cout)] = h;
             }
         }
         return;
@@ -502,7 +558,7 @@ __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int 
             __syncthreads();
 #pragma unroll 4
             for (int r = ty; r < 64; r += 4)                       // row = input channel, 64 consecutive output channels
-                w16_rot[((size_t)(ci0 + r) * RS + (RS - 1 - tap)) * Cout + co0 + tx] = tile[tx][r];
+                w16_rot[conv_prep_rot_index(rot_mode, ci0 + r, tap, co0 + tx, RS, Cin, Cout)] = tile[tx][r];
             __syncthreads();
         }
     }
@@ -510,16 +566,16 @@ __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int 
 
 __global__ void __launch_bounds__(DIR_TPB)
 conv_prep_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, uint16_t* __restrict__ w16,
-                         uint16_t* __restrict__ w16_rot) {
-    conv_prep_body(w, Cout, RS, Cin, w16, w16_rot);
+                         uint16_t* __restrict__ w16_rot, int rot_mode) {
+    conv_prep_body(w, Cout, RS, Cin, w16, w16_rot, rot_mode);
 }
 
 // blockIdx.y = layer; the layer's row of the table holds its pointers and extents
 __global__ void __launch_bounds__(DIR_TPB)
 conv_prep_weights_batched_kernel(const long long* __restrict__ table) {
-    const long long* e = table + (size_t)blockIdx.y * 6;
+    const long long* e = table + (size_t)blockIdx.y * 7;
     conv_prep_body(reinterpret_cast<const float*>(e[0]), (int)e[3], (int)e[4], (int)e[5],
-                   reinterpret_cast<uint16_t*>(e[1]), reinterpret_cast<uint16_t*>(e[2]));
+                   reinterpret_cast<uint16_t*>(e[1]), reinterpret_cast<uint16_t*>(e[2]), (int)e[6]);
 }
 }  // namespace
 
@@ -531,13 +587,21 @@ extern "C" int dir_conv_prep_weights_batched(const void* table, int nlayers, dir
     return DIR_OK;
 }
 
+extern "C" int dir_conv_prep_weights_ex(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
+                                        int rot_mode, dir_stream_t stream);
 extern "C" int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
                                      dir_stream_t stream) {
+    return dir_conv_prep_weights_ex(w, Cout, R, S, Cin, w16, w16_rot, 0, stream);
+}
+
+extern "C" int dir_conv_prep_weights_ex(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
+                                        int rot_mode, dir_stream_t stream) {
     DIR_RETURN_IF(!w || !w16 || Cout <= 0 || R <= 0 || S <= 0 || Cin <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(rot_mode < 0 || rot_mode > 1 || (rot_mode == 1 && (R != 3 || S != 3)), DIR_EINVAL);
     const size_t n = (size_t)Cout * R * S * Cin;
     int grid = dir_cdiv((long long)n, DIR_TPB); if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(conv_prep_weights_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), w, Cout, R * S, Cin,
-                       static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16_rot));
+                       static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16_rot), rot_mode);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

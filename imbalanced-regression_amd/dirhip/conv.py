@@ -124,7 +124,14 @@ class _ConvFn(torch.autograd.Function):
             dalias = None
             need_dx = False
         dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
-        if need_dx:                                                              # strided data gradient: library kernel for now
+        if need_dx and w16_rot is not None and w16_rot.dim() == 1 and ctx.stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            # 3x3 / stride 2 / pad 1: four stride-1 launches, one per output-pixel parity class (dir_conv_dgrad_s2)
+            n_, cin_, h_, w_ = x.shape
+            dx = torch.empty((n_, cin_, h_, w_), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
+                                              L.stream_ptr(x.device)), "dir_conv_dgrad_s2")
+            need_dx = False
+        if need_dx:                                                              # other strided data gradients: library kernel
             dx = torch.ops.aten.convolution_backward(
                 dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
                 [True, False, False])[0]
@@ -194,9 +201,13 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_hook(invalidate_weight_cache)
 
 
+import os as _os
+_S2_DGRAD = "s2_dgrad" not in _os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")
+
+
 class _PreparedWeights:
     """bf16 operands of one conv layer (persistent buffers) + the key of the master weight they were made from."""
-    __slots__ = ("key", "w16", "w16_rot", "conv_ref", "shape")
+    __slots__ = ("key", "w16", "w16_rot", "conv_ref", "shape", "rot_mode")
 
     def __init__(self, conv):
         import weakref
@@ -205,7 +216,12 @@ class _PreparedWeights:
         self.shape = (cout, r * s, cin)
         self.w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
         self.w16_rot = None
-        if (conv.stride[0] == 1 or (r == 1 and s == 1)) and supported(cout, cin):
+        self.rot_mode = 0
+        if conv.stride[0] == 2 and (r, s) == (3, 3) and conv.padding[0] == 1 and supported(cout, cin) and _S2_DGRAD:
+            # the four parity-class weights of the stride-2 data gradient, packed (dir_conv_dgrad_s2)
+            self.w16_rot = torch.empty(cin * 9 * cout, dtype=torch.bfloat16, device=w.device)
+            self.rot_mode = 1
+        elif (conv.stride[0] == 1 or (r == 1 and s == 1)) and supported(cout, cin):
             # [Cin][R][S][Cout], taps rotated by 180 degrees: the weight of the data-gradient convolution
             self.w16_rot = torch.empty((cin, cout, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
         self.key = None
@@ -239,7 +255,7 @@ def _refresh_all(device):
     cached = _TABLES.get(device)
     if cached is None or cached[0] != ptrs:
         rows = [[w.data_ptr(), st.w16.data_ptr(), 0 if st.w16_rot is None else st.w16_rot.data_ptr(),
-                 st.shape[0], st.shape[1], st.shape[2]] for st, w in live]
+                 st.shape[0], st.shape[1], st.shape[2], st.rot_mode] for st, w in live]
         cached = (ptrs, torch.tensor(rows, dtype=torch.int64).to(device))
         _TABLES[device] = cached
     L.check(L.lib().dir_conv_prep_weights_batched(L.ptr(cached[1]), len(live), L.stream_ptr(device)),
@@ -267,8 +283,8 @@ def _prepared(conv):
             wd = wd.contiguous(memory_format=torch.channels_last)
         cout, rs, cin = st.shape
         r = conv.kernel_size[0]
-        L.check(L.lib().dir_conv_prep_weights(L.ptr(wd), cout, r, rs // r, cin, L.ptr(st.w16), L.ptr(st.w16_rot),
-                                              L.stream_ptr(wd.device)), "dir_conv_prep_weights")
+        L.check(L.lib().dir_conv_prep_weights_ex(L.ptr(wd), cout, r, rs // r, cin, L.ptr(st.w16), L.ptr(st.w16_rot), st.rot_mode,
+                                                 L.stream_ptr(wd.device)), "dir_conv_prep_weights")
         st.key = key
     return st.w16, st.w16_rot
 

@@ -247,8 +247,18 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
                           dir_stream_t stream);
 /* The same for all layers of a network in ONE launch (52 launches per optimizer step otherwise).  table: device
- * array [nlayers][6] of int64: { w (const float*), w16, w16_rot (0 = none), Cout, R*S, Cin }. */
+ * array [nlayers][7] of int64: { w (const float*), w16, w16_rot (0 = none), Cout, R*S, Cin, rot_mode }. */
 int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t stream);
+/* rot_mode 0: as dir_conv_prep_weights.  rot_mode 1 (3x3): w16_rot receives the four parity-class weights of the
+ * STRIDE-2 data gradient, packed back to back (class (a, b), a = row parity, b = column parity of the output pixel:
+ * (1 + a)(1 + b) taps, [Cin][taps][Cout]; bases at 0, 1, 3, 5 taps x Cin x Cout) — the operand of dir_conv_dgrad_s2. */
+int dir_conv_prep_weights_ex(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot, int rot_mode,
+                             dir_stream_t stream);
+/* Data gradient of a 3x3 / stride-2 / pad-1 convolution (conv2 of the first block of stages 2-4, resnet.py:46-47) as
+ * four stride-1 launches of the implicit-GEMM kernel, one per output-pixel parity class: dx[n, 2i+a, 2j+b, :] =
+ * sum over the class's taps of dY[n, i+dr, j+ds, :] * W.  Every dx element is written exactly once: no zero fill, no
+ * atomics.  dy [N, Ho, Wo, Cy] bf16, dx [N, 2 Ho, 2 Wo, Cx] bf16, wcls from dir_conv_prep_weights_ex(rot_mode = 1). */
+int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx, dir_stream_t stream);
 int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 /* y = bf16(bf16(conv(x, w)) + addend): the gradient accumulation autograd would run as a separate add kernel at a

@@ -233,11 +233,22 @@ def test_batched_weight_preparation_matches_single_layer_path():
         w = c.weight.detach()
         assert not torch.equal(st.w16, old)
         assert torch.equal(st.w16, w.to(torch.bfloat16))
-        if st.w16_rot is not None:
+        if st.rot_mode == 0:
             ref_rot = w.to(torch.bfloat16).flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
             assert torch.equal(st.w16_rot, ref_rot)
         else:
+            # stride-2 3x3: four parity-class weights [Cin][taps][Cout], packed (0,0) (0,1) (1,0) (1,1); tap (dr, ds) of a
+            # class is filter element (r, s) = (1 | 2,0)[a][dr], likewise s
             assert c.stride[0] == 2
+            w16 = w.to(torch.bfloat16)
+            pieces = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    rs = [1] if a == 0 else [2, 0]
+                    ss = [1] if b == 0 else [2, 0]
+                    sub = w16[:, :, rs][:, :, :, ss]                          # [Cout, Cin, R', S']
+                    pieces.append(sub.permute(1, 2, 3, 0).contiguous().reshape(-1))   # [Cin][R'][S'][Cout]
+            assert torch.equal(st.w16_rot, torch.cat(pieces))
 
 
 def test_deferred_relu_backward_is_bit_identical():
@@ -324,3 +335,27 @@ def test_stem_conv_matches_fp32_reference(shape):
     y2, _ = stem_conv(x, conv, want_stats=False)
     ref2 = F.conv2d(x.to(torch.bfloat16).float(), conv.weight.detach().to(torch.bfloat16).float(), None, 2, 3)
     assert_close(y2.float().detach().cpu().numpy(), ref2.cpu().numpy(), rtol=4e-3, atol_scale=2e-3, msg="y after step")
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 56, 56, 128), (3, 64, 8, 12, 192), (1, 256, 2, 2, 64)])
+def test_stride2_3x3_data_gradient_by_parity_classes(shape):
+    """dir_conv_dgrad_s2 (four stride-1 launches, one per output-pixel parity class) vs autograd of F.conv2d in fp32."""
+    import torch.nn as nn
+    from dirhip.conv import conv_bn_input
+    n, cin, h, w, cout = shape
+    torch.manual_seed(9)
+    conv = nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(51)
+    x0 = torch.randn(n, cin, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = x0.clone().requires_grad_(True)
+    y, _ = conv_bn_input(x, conv, want_stats=False)
+    assert conv._dir_w16.rot_mode == 1
+    dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    xr = x0.float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    F.conv2d(xr, wr, None, 2, 1).backward(dy.float())
+    assert x.grad.shape == xr.grad.shape and x.grad.dtype == torch.bfloat16
+    assert_close(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
+    rel = ((conv.weight.grad - wr.grad).norm() / wr.grad.norm()).item()
+    assert rel < 1e-2, rel
