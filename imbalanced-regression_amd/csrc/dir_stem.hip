@@ -159,6 +159,140 @@ stem_prep_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp)
     wp[i] = (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2)) & 0xffffu);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem: dW[co][r][s][c] = sum over (n, ho, wo) of dY[n, ho, wo, co] * X[n, 2 ho - 3 + r, 2 wo - 3 + s, c].
+// Per output row the contraction index is wo, and with the 24-element windows of the forward kernel the gradient of
+// filter row r is D[(r, t)][co] = sum_wo in_r[6 wo + 4 + t] * dY[wo][co]: a GEMM with M = 7 x 24 = 168 window positions
+// (6 MFMA tiles of 32), N = 64 channels, K = 128 pixels per row. The dY row is transposed on the way into LDS (4 pixels x 8
+// channels per thread, v_perm_b32, 8-byte stores) so that its MFMA operand is one ds_read_b128; the image operand has
+// a 12-byte stride between consecutive pixels and is gathered with eight 16-bit LDS reads per fragment. Workgroups are
+// persistent over output rows and keep their accumulators in registers; each writes ONE partial [168][64] float tile,
+// summed in workgroup order by a second kernel that also drops the zero-weight window column and emits
+// [64][7][7][3]: deterministic, no atomics.
+constexpr int SW_DROWB = 272;                      // bytes per channel row of the transposed dY tile: 128 pixels x 2 B + pad
+constexpr int SW_D_BYTES = ST_COUT * SW_DROWB;     // 17 408
+constexpr int SW_LDS = ST_IN_BYTES + SW_D_BYTES;   // 28 608 B
+constexpr int SW_M = ST_R * 24;                    // 168 window positions
+constexpr int SW_MAX_BLOCKS = 1024;
+
+struct StemWgP { const uint16_t* dy; const uint16_t* x; float* part; int N, H, W, Ho, Wo, rows; };
+
+__global__ void __launch_bounds__(DIR_TPB)
+stem_wgrad_kernel(StemWgP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* in = smem;
+    unsigned char* dt = smem + ST_IN_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, frow = lane & 31, fhalf = lane >> 5;
+    for (int i = t; i < ST_IN_BYTES / 16; i += DIR_TPB) *reinterpret_cast<u32x4*>(in + i * 16) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int chunks = p.W * ST_CIN * 2 / 16;
+    const int pg = t >> 3, cg = t & 7;                              // dY staging: pixels 4 pg .. + 3, channels 8 cg .. + 7
+    // M tiles of this wavefront: waves 0, 1 own tiles (w, w + 4), waves 2, 3 own tile w alone (6 tiles of 32 rows)
+    const int nmt = wave < 2 ? 2 : 1;
+    int abase[2];                                                   // byte offset of this lane's A row: filter row + window element
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = (wave + 4 * j) * 32 + frow;
+        const int r = m / 24 > ST_R - 1 ? ST_R - 1 : m / 24, tt = m - 24 * (m / 24);     // rows >= 168: junk, never stored
+        abase[j] = r * ST_ROWB + (4 + tt) * 2;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][ni][e] = 0.0f;
+
+    for (int row = blockIdx.x; row < p.rows; row += gridDim.x) {
+        const int n = row / p.Ho, ho = row - n * p.Ho;
+        for (int i = t; i < ST_R * chunks; i += DIR_TPB) {          // the 7 input rows, as in the forward kernel
+            const int r = i / chunks, j = i - r * chunks;
+            const int hi = 2 * ho - 3 + r;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)hi < (unsigned)p.H) v = *reinterpret_cast<const u32x4*>(p.x + ((size_t)(n * p.H + hi) * p.W) * ST_CIN + j * 8);
+            *reinterpret_cast<u32x4*>(in + r * ST_ROWB + 32 + j * 16) = v;
+        }
+        {                                                           // dY row -> [channel][pixel] (4 x 8 transposes in registers)
+            const uint16_t* src = p.dy + ((size_t)row * p.Wo + 4 * pg) * ST_COUT + cg * 8;
+            u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = r0, r2 = r0, r3 = r0;
+            if (4 * pg + 0 < p.Wo) r0 = *reinterpret_cast<const u32x4*>(src);
+            if (4 * pg + 1 < p.Wo) r1 = *reinterpret_cast<const u32x4*>(src + ST_COUT);
+            if (4 * pg + 2 < p.Wo) r2 = *reinterpret_cast<const u32x4*>(src + 2 * ST_COUT);
+            if (4 * pg + 3 < p.Wo) r3 = *reinterpret_cast<const u32x4*>(src + 3 * ST_COUT);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // v_perm_b32(src0 = high dword, src1 = low dword): 0x05040100 -> lo16(src1) | lo16(src0) << 16
+                const uint32_t lo01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x05040100u), lo23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x05040100u);
+                const uint32_t hi01 = __builtin_amdgcn_perm(r1[q], r0[q], 0x07060302u), hi23 = __builtin_amdgcn_perm(r3[q], r2[q], 0x07060302u);
+                *reinterpret_cast<uint2*>(dt + (cg * 8 + 2 * q) * SW_DROWB + pg * 8) = make_uint2(lo01, lo23);
+                *reinterpret_cast<uint2*>(dt + (cg * 8 + 2 * q + 1) * SW_DROWB + pg * 8) = make_uint2(hi01, hi23);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {                            // 16 pixels per step: this lane's 8 are wo0 .. wo0 + 7
+            const int wo0 = ks * 16 + 8 * fhalf;
+            bf16x8 b[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(dt + (ni * 32 + frow) * SW_DROWB + wo0 * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j < nmt) {
+                    const unsigned char* ap = in + abase[j] + 12 * wo0;
+                    u32x4 av;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        av[q] = (uint32_t)*reinterpret_cast<const uint16_t*>(ap + 24 * q) |
+                                ((uint32_t)*reinterpret_cast<const uint16_t*>(ap + 24 * q + 12) << 16);
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ni], acc[j][ni], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                            // everyone is done with `in` / `dt` before the next row lands
+    }
+
+    // partial tile of this workgroup: part[block][168][64]; C/D: col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    float* out = p.part + (size_t)blockIdx.x * SW_M * ST_COUT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (j < nmt)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (wave + 4 * j) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                    if (m < SW_M) out[m * ST_COUT + ni * 32 + frow] = acc[j][ni][e];
+                }
+}
+
+// dW[co][r][s][c] = sum over workgroups (in index order) of part[b][r * 24 + (s + 1) * 3 + c][co]
+__global__ void __launch_bounds__(DIR_TPB)
+stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw) {
+    const int i = blockIdx.x * DIR_TPB + threadIdx.x;               // (k = (r, s, c), co): co fastest for coalesced reads
+    if (i >= ST_R * ST_R * ST_CIN * ST_COUT) return;
+    const int co = i % ST_COUT, k = i / ST_COUT;
+    const int r = k / 21, sc = k - 21 * r;                          // sc = s * 3 + c
+    const int m = r * 24 + 3 + sc;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;               // four interleaved chains, combined in a fixed order
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        s0 += part[((size_t)(b + 0) * SW_M + m) * ST_COUT + co];
+        s1 += part[((size_t)(b + 1) * SW_M + m) * ST_COUT + co];
+        s2 += part[((size_t)(b + 2) * SW_M + m) * ST_COUT + co];
+        s3 += part[((size_t)(b + 3) * SW_M + m) * ST_COUT + co];
+    }
+    for (; b < nblocks; ++b) s0 += part[((size_t)b * SW_M + m) * ST_COUT + co];
+    dw[(size_t)co * (ST_R * ST_R * ST_CIN) + k] = (s0 + s1) + (s2 + s3);
+}
+
+int stem_wgrad_grid(int N, int Ho) {
+    const long long rows = (long long)N * Ho;
+    return (int)(rows < SW_MAX_BLOCKS ? rows : SW_MAX_BLOCKS);
+}
+
 int stem_grid(int N, int Ho) {
     const long long rows = (long long)N * Ho;
     return (int)(rows < ST_MAX_BLOCKS ? rows : ST_MAX_BLOCKS);
@@ -197,3 +331,30 @@ extern "C" int dir_stem_conv_fwd(const void* x, const void* wpack, void* y, floa
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
+
+extern "C" size_t dir_stem_conv_wgrad_workspace(int N, int H) {
+    if (N <= 0 || H <= 0) return 0;
+    return dir_align_up(sizeof(float) * (size_t)stem_wgrad_grid(N, (H + 6 - 7) / 2 + 1) * SW_M * ST_COUT, 256);
+}
+
+extern "C" int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, void* workspace,
+                                   size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !x || !dw || !workspace || N <= 0 || H <= 0 || W <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || !dir_aligned16(dw) || !dir_aligned16(workspace), DIR_EINVAL);
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    DIR_RETURN_IF(Wo > 128 || W % 8 != 0 || 16 + 3 * W > ST_ROWE, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF((long long)N * H * W * ST_CIN >= (1ll << 31) || (long long)N * Ho * Wo * ST_COUT >= (1ll << 31), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(workspace_bytes < dir_stem_conv_wgrad_workspace(N, H), DIR_EWORKSPACE);
+    StemWgP p;
+    p.dy = static_cast<const uint16_t*>(dy); p.x = static_cast<const uint16_t*>(x); p.part = static_cast<float*>(workspace);
+    p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.rows = N * Ho;
+    const int grid = stem_wgrad_grid(N, Ho);
+    hipStream_t s = dir_s(stream);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(DIR_TPB), SW_LDS, s, p);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(dir_cdiv(ST_R * ST_R * ST_CIN * ST_COUT, DIR_TPB)), dim3(DIR_TPB), 0, s,
+                       p.part, grid, dw);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dir_stem_conv_stats_rows": (c_size_t, [c_int, c_int]),
     "dir_stem_conv_prep_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dir_stem_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dir_stem_conv_wgrad_workspace": (c_size_t, [c_int, c_int]),
+    "dir_stem_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_dgrad_join": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "dir_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_void_p]),

@@ -203,6 +203,7 @@ _reg_post_hook(invalidate_weight_cache)
 
 import os as _os
 _S2_DGRAD = "s2_dgrad" not in _os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")
+_STEM_WGRAD = "stem_wgrad" not in _os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")
 
 
 class _PreparedWeights:
@@ -342,7 +343,7 @@ def projection_pair_ok(conv1, conv_d):
 
 class _StemConvFn(torch.autograd.Function):
     """7x7 / stride-2 stem convolution on a bf16 channels_last image: forward = ``dir_stem_conv_fwd`` (+ BatchNorm partial
-    statistics), weight gradient = library kernel for now; the image needs no gradient."""
+    statistics), weight gradient = ``dir_stem_conv_wgrad``; the image needs no gradient."""
 
     @staticmethod
     def forward(ctx, x16, weight, wpack, want_stats):
@@ -365,9 +366,16 @@ class _StemConvFn(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
-        w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dw = torch.ops.aten.convolution_backward(dy, x16, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                                 [False, True, False])[1]
+        n, _, h, w = x16.shape
+        if _STEM_WGRAD:
+            dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x16.device, memory_format=torch.channels_last)
+            ws = torch.empty(L.lib().dir_stem_conv_wgrad_workspace(n, h), dtype=torch.uint8, device=x16.device)
+            L.check(L.lib().dir_stem_conv_wgrad(L.ptr(dy), L.ptr(x16), L.ptr(dw), n, h, w, L.ptr(ws), ws.numel(),
+                                                L.stream_ptr(x16.device)), "dir_stem_conv_wgrad")
+        else:
+            w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dy, x16, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
         return None, dw.to(weight.dtype), None, None
 
 

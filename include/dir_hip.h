@@ -289,6 +289,12 @@ int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const 
 size_t dir_stem_conv_stats_rows(int N, int H);
 int dir_stem_conv_prep_weights(const float* w, void* wpack /* [64][176] bf16 */, dir_stream_t stream);
 int dir_stem_conv_fwd(const void* x, const void* wpack, void* y, float* stats, int N, int H, int W, dir_stream_t stream);
+/* Weight gradient of the stem convolution: dy [N, Ho, Wo, 64] bf16, x [N, H, W, 3] bf16 -> dw [64][7][7][3] f32 (the
+ * channels_last layout of the [64, 3, 7, 7] parameter).  Persistent MFMA kernel (K = the pixels of an output row) + a
+ * fixed-order reduction over workgroups: deterministic.  workspace >= dir_stem_conv_wgrad_workspace(N, H) bytes. */
+size_t dir_stem_conv_wgrad_workspace(int N, int H);
+int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, void* workspace,
+                        size_t workspace_bytes, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the
