@@ -268,24 +268,27 @@ stem_wgrad_kernel(StemWgP p) {
                 }
 }
 
-// dW[co][r][s][c] = sum over workgroups (in index order) of part[b][r * 24 + (s + 1) * 3 + c][co]
+// dW[co][r][s][c] = sum over workgroups of part[b][r * 24 + (s + 1) * 3 + c][co]. One workgroup per filter element k =
+// (r, s, c): 64 channels x 4 lanes, lane l adds workgroups l, l + 4, ... in four interleaved chains (independent loads in
+// flight), the lane sums are combined in lane order: a fixed summation tree, bit-reproducible.
 __global__ void __launch_bounds__(DIR_TPB)
 stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw) {
-    const int i = blockIdx.x * DIR_TPB + threadIdx.x;               // (k = (r, s, c), co): co fastest for coalesced reads
-    if (i >= ST_R * ST_R * ST_CIN * ST_COUT) return;
-    const int co = i % ST_COUT, k = i / ST_COUT;
+    __shared__ float sh[4][ST_COUT];
+    const int k = blockIdx.x, co = threadIdx.x & (ST_COUT - 1), l = threadIdx.x / ST_COUT;
     const int r = k / 21, sc = k - 21 * r;                          // sc = s * 3 + c
     const int m = r * 24 + 3 + sc;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;               // four interleaved chains, combined in a fixed order
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = l;
+    for (; b + 12 < nblocks; b += 16) {
         s0 += part[((size_t)(b + 0) * SW_M + m) * ST_COUT + co];
-        s1 += part[((size_t)(b + 1) * SW_M + m) * ST_COUT + co];
-        s2 += part[((size_t)(b + 2) * SW_M + m) * ST_COUT + co];
-        s3 += part[((size_t)(b + 3) * SW_M + m) * ST_COUT + co];
+        s1 += part[((size_t)(b + 4) * SW_M + m) * ST_COUT + co];
+        s2 += part[((size_t)(b + 8) * SW_M + m) * ST_COUT + co];
+        s3 += part[((size_t)(b + 12) * SW_M + m) * ST_COUT + co];
     }
-    for (; b < nblocks; ++b) s0 += part[((size_t)b * SW_M + m) * ST_COUT + co];
-    dw[(size_t)co * (ST_R * ST_R * ST_CIN) + k] = (s0 + s1) + (s2 + s3);
+    for (; b < nblocks; b += 4) s0 += part[((size_t)b * SW_M + m) * ST_COUT + co];
+    sh[l][co] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (l == 0) dw[(size_t)co * (ST_R * ST_R * ST_CIN) + k] = (sh[0][co] + sh[1][co]) + (sh[2][co] + sh[3][co]);
 }
 
 int stem_wgrad_grid(int N, int Ho) {
@@ -352,8 +355,7 @@ extern "C" int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int
     hipStream_t s = dir_s(stream);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(DIR_TPB), SW_LDS, s, p);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(dir_cdiv(ST_R * ST_R * ST_CIN * ST_COUT, DIR_TPB)), dim3(DIR_TPB), 0, s,
-                       p.part, grid, dw);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ST_R * ST_R * ST_CIN), dim3(DIR_TPB), 0, s, p.part, grid, dw);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
