@@ -1,5 +1,7 @@
-"""GPU probe: dir_conv_fwd on every ResNet-50 conv shape (forward shapes and the stride-1 data-gradient shapes) at batch B.
-Run once per kernel configuration (DIR_CONV_MODE / DIR_CONV_PER_CU / DIR_CONV_NBUF are read once per process)."""
+"""GPU probe: dir_conv_fwd / dir_conv_wgrad on every ResNet-50 conv shape (forward shapes, the stride-1 data-gradient
+shapes and the weight gradients) at batch B; PROBE_ROWS=1 prints the per-layer table. Run once per kernel configuration:
+the experiment switches (DIR_CONV_PF, DIR_CONV_PF_KT, DIR_CONV_NBUF, DIR_CONV_NBUF_KT, DIR_WGRAD_ROUNDS, DIR_BN_CAP) are
+read once per process."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
