@@ -1,0 +1,171 @@
+"""CPU restatements of the index arithmetic the HIP convolution kernels rely on, checked against torch's own
+convolutions in float64. They pin the formulas (not the kernels — those are compared on the GPU in test_hip_conv.py):
+
+  * the incremental im2col walk of the weight-gradient kernel (csrc/dir_conv_wgrad.hip: WgWalk / wg_advance and the
+    constants dir_conv_wgrad() derives) against a direct (n, ho, wo) decode, for ordinary and degenerate geometries;
+  * the decomposition of a 3x3 / stride-2 / pad-1 data gradient into four stride-1 convolutions by output-pixel parity,
+    with the class-packed weight layout of conv_prep_rot_index (csrc/dir_conv.hip), against autograd;
+  * the compact stride-2 1x1 gradient added at the even pixels (dir_conv_dgrad_join) against autograd;
+  * the 24-element row windows and packed weights of the stem kernels (csrc/dir_stem.hip), forward and weight gradient.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _walk_consts(H, W, Cin, R, S, stride, pad):
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    dw, dh, dn = 64 % Wo, (64 // Wo) % Ho, 64 // (Wo * Ho)
+    return dict(Ho=Ho, Wo=Wo, WoS=Wo * stride, HoS=Ho * stride, c1=(stride * W - Wo * stride) * Cin * 2,
+                c2=(H * W - Ho * stride * W) * Cin * 2, dws64=dw * stride, dhs64=dh * stride, dn64=dn,
+                c64=(dn * H * W + dh * stride * W + dw * stride) * Cin * 2, cstep=stride * Cin * 2)
+
+
+def _advance(st, c, stride, dws, dhs, dn, cbase):                 # wg_advance
+    n, hs, ws, off = st
+    ws += dws
+    carry1 = ws >= c["WoS"]
+    if carry1:
+        ws -= c["WoS"]
+    hs += dhs + (stride if carry1 else 0)
+    carry2 = hs >= c["HoS"]
+    if carry2:
+        hs -= c["HoS"]
+    return (n + dn + (1 if carry2 else 0), hs, ws, off + cbase + (c["c1"] if carry1 else 0) + (c["c2"] if carry2 else 0))
+
+
+def _direct(m, H, W, Cin, stride, c, trp, tsp, coff):
+    n, ho, wo = m // (c["Ho"] * c["Wo"]), (m // c["Wo"]) % c["Ho"], m % c["Wo"]
+    hs, ws = ho * stride, wo * stride
+    return (n, hs, ws, (((n * H + hs + trp) * W + ws + tsp) * Cin + coff) * 2)
+
+
+@pytest.mark.parametrize("geo", [(56, 56, 3, 3, 1, 1), (56, 56, 3, 3, 2, 1), (14, 14, 3, 3, 1, 1), (7, 7, 3, 3, 1, 1), (9, 13, 3, 3, 1, 1),
+                                 (5, 3, 3, 3, 2, 1), (112, 112, 3, 3, 1, 1), (224, 224, 3, 3, 2, 1), (1, 1, 1, 1, 1, 0), (56, 56, 1, 1, 2, 0),
+                                 (3, 200, 3, 3, 1, 1), (200, 3, 3, 3, 1, 1), (8, 12, 3, 3, 2, 1), (2, 2, 3, 3, 2, 1)])
+def test_incremental_im2col_walk_equals_direct_decode(geo):
+    H, W, R, S, stride, pad = geo
+    Cin = 64
+    c = _walk_consts(H, W, Cin, R, S, stride, pad)
+    rows = 3 * c["Ho"] * c["Wo"] + 7
+    for tr in range(R):
+        for ts in range(S):
+            trp, tsp = tr - pad, ts - pad
+            for start in (0, 4, 200):                            # first row of a thread: any multiple of 4
+                st, m = _direct(start, H, W, Cin, stride, c, trp, tsp, 8), start
+                for _ in range(rows // 64 + 2):                  # K-steps
+                    w = st
+                    for j in range(4):                           # the thread's 4 consecutive rows
+                        assert w == _direct(m + j, H, W, Cin, stride, c, trp, tsp, 8), (geo, tr, ts, m + j)
+                        if j < 3:
+                            w = _advance(w, c, stride, stride, 0, 0, c["cstep"])
+                    st, m = _advance(st, c, stride, c["dws64"], c["dhs64"], c["dn64"], c["c64"]), m + 64
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _rot_index_s2(ci, tap, co, Cin, Cout):                        # conv_prep_rot_index, rot_mode 1
+    r, s = tap // 3, tap % 3
+    a, b, dr, ds = int(r != 1), int(s != 1), int(r == 0), int(s == 0)
+    taps, t = (1 + a) * (1 + b), dr * (1 + b) + ds
+    base = (5 if b else 3) if a else (1 if b else 0)
+    return base * Cin * Cout + (ci * taps + t) * Cout + co
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 12, 7), (1, 3, 2, 2, 4), (2, 4, 6, 6, 3)])
+def test_stride2_dgrad_parity_classes_and_weight_packing(shape):
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, wt, None, 2, 1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ho, wo = h // 2, w // 2
+    # class-packed weights exactly as the prep kernel places them
+    packed = np.zeros(cin * 9 * cout)
+    wn = wt.numpy()
+    for co in range(cout):
+        for ci in range(cin):
+            for tap in range(9):
+                packed[_rot_index_s2(ci, tap, co, cin, cout)] = wn[co, ci, tap // 3, tap % 3]
+    dyn = np.zeros((n, ho + 1, wo + 1, cout))                     # zero beyond the bottom / right edge
+    dyn[:, :ho, :wo] = dy.permute(0, 2, 3, 1).numpy()
+    dx = np.zeros((n, h, w, cin))
+    tap_base = [0, 1, 3, 5]
+    for a in (0, 1):
+        for b in (0, 1):
+            taps = (1 + a) * (1 + b)
+            wc = packed[tap_base[a * 2 + b] * cin * cout:][:cin * taps * cout].reshape(cin, 1 + a, 1 + b, cout)
+            acc = np.zeros((n, ho, wo, cin))
+            for dr in range(1 + a):
+                for ds in range(1 + b):
+                    acc += np.einsum("nhwo,io->nhwi", dyn[:, dr:dr + ho, ds:ds + wo], wc[:, dr, ds])
+            dx[:, a::2, b::2] = acc                                # written exactly once
+    np.testing.assert_allclose(dx, x.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_compact_stride2_1x1_gradient_added_at_even_pixels():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 6, 8, 10, generator=g, dtype=torch.float64, requires_grad=True)
+    w1 = torch.randn(4, 6, 1, 1, generator=g, dtype=torch.float64)
+    wd = torch.randn(5, 6, 1, 1, generator=g, dtype=torch.float64)
+    y1, yd = F.conv2d(x, w1), F.conv2d(x, wd, None, 2)
+    dy1 = torch.randn(y1.shape, generator=g, dtype=torch.float64)
+    dyd = torch.randn(yd.shape, generator=g, dtype=torch.float64)
+    (y1 * dy1).sum().backward(retain_graph=True)
+    (yd * dyd).sum().backward()
+    compact = torch.einsum("nohw,oi->nihw", dyd, wd[:, :, 0, 0])  # plain 1x1 GEMM on dY of the strided conv
+    dx = torch.einsum("nohw,oi->nihw", dy1, w1[:, :, 0, 0])
+    dx[:, :, ::2, ::2] += compact
+    torch.testing.assert_close(dx, x.grad, rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+ROWE, COL0 = 800, 16                                              # staged row image: column 0 at element 16
+
+
+def _stem_rows(x_nhwc, n, ho):
+    H, W = x_nhwc.shape[1], x_nhwc.shape[2]
+    img = np.zeros((7, ROWE))
+    for r in range(7):
+        hi = 2 * ho - 3 + r
+        if 0 <= hi < H:
+            img[r, COL0:COL0 + 3 * W] = x_nhwc[n, hi].reshape(-1)
+    return img
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 9, 8)])
+def test_stem_row_windows_and_packed_weights(shape):
+    n, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 3, H, W, generator=g, dtype=torch.float64)
+    wt = torch.randn(64, 3, 7, 7, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, wt, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xn = x.permute(0, 2, 3, 1).numpy()
+    wn = wt.detach().permute(0, 2, 3, 1).numpy()                  # [co][r][s][c]
+    wp = np.zeros((64, 176))                                      # stem_prep_weights_kernel
+    for r in range(7):
+        for s in range(7):
+            for c in range(3):
+                wp[:, r * 24 + (s + 1) * 3 + c] = wn[:, r, s, c]
+    yk = np.zeros((n, Ho, Wo, 64))
+    D = np.zeros((168, 64))                                       # weight-gradient tile [(r, t)][co]
+    dyn = dy.permute(0, 2, 3, 1).numpy()
+    for b in range(n):
+        for ho in range(Ho):
+            img = _stem_rows(xn, b, ho)
+            for wo in range(Wo):
+                win = np.concatenate([img[r, 4 + 6 * wo:4 + 6 * wo + 24] for r in range(7)])   # 168 window elements
+                yk[b, ho, wo] = wp[:, :168] @ win
+                D += np.outer(win, dyn[b, ho, wo])
+    np.testing.assert_allclose(yk, y.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-12, atol=1e-12)
+    dw = np.zeros((64, 7, 7, 3))                                  # stem_wgrad_reduce_kernel's mapping
+    for r in range(7):
+        for sc in range(21):
+            dw[:, r, sc // 3, sc % 3] = D[r * 24 + 3 + sc]
+    np.testing.assert_allclose(dw, wt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-11, atol=1e-11)
