@@ -169,3 +169,25 @@ def test_stem_row_windows_and_packed_weights(shape):
         for sc in range(21):
             dw[:, r, sc // 3, sc % 3] = D[r * 24 + 3 + sc]
     np.testing.assert_allclose(dw, wt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-11, atol=1e-11)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [7, 13, 14, 28, 56, 112, 127, 224, 1000])
+def test_float_reciprocal_division_is_exact_below_2_to_24(d):
+    """The kernels decode m -> (n, ho, wo) with a float32 multiply by 1/d, a truncation and ONE correction step
+    (csrc/dir_conv.hip, dir_conv_wgrad.hip: 'exact for m < 2^24', enforced by the C-ABI's M < 2^24 check). Checked here at
+    every multiple of d and its two neighbours, where a wrong rounding would show, plus random m."""
+    def decode(m):
+        inv = np.float32(1.0) / np.float32(d)
+        q = (m.astype(np.float32) * inv).astype(np.int64)
+        r = m - q * d
+        lo = r < 0
+        q, r = np.where(lo, q - 1, q), np.where(lo, r + d, r)
+        hi = r >= d
+        return np.where(hi, q + 1, q), np.where(hi, r - d, r)
+    k = np.arange(0, (1 << 24) // d + 1, dtype=np.int64)
+    ms = [k * d + delta for delta in (-1, 0, 1)] + [np.random.default_rng(d).integers(0, 1 << 24, 100000)]
+    for m in ms:
+        m = m[(m >= 0) & (m < (1 << 24))]
+        q, r = decode(m)
+        assert np.array_equal(q, m // d) and np.array_equal(r, m % d)
