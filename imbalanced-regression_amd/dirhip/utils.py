@@ -5,11 +5,12 @@ Kernel-backed: ``calibrate_mean_var`` (utils.py:97-107). Host, bit-exact: ``get_
 (``AverageMeter`` ... ``save_checkpoint``) are plain host utilities ``train.py`` star-imports, together with
 the names ``torch`` / ``np`` / ``os`` / ``logging`` / ``shutil`` it relies on.
 """
+import logging
 import os
 import shutil
-import torch
-import logging
+
 import numpy as np
+import torch
 from scipy.ndimage import gaussian_filter1d
 from scipy.signal.windows import triang
 
@@ -28,9 +29,8 @@ class AverageMeter(object):
         self.val = self.avg = self.sum = self.count = 0
 
     def update(self, val, n=1):
-        self.val = val
+        self.val, self.count = val, self.count + n
         self.sum += val * n
-        self.count += n
         self.avg = self.sum / self.count
 
     def __str__(self):
@@ -92,11 +92,12 @@ def adjust_learning_rate(optimizer, epoch, args):
 
 def save_checkpoint(args, state, is_best, prefix=''):
     """utils.py:89-94: <store_root>/<store_name>/ckpt.pth.tar (+ ckpt.best.pth.tar)."""
-    filename = f"{args.store_root}/{args.store_name}/{prefix}ckpt.pth.tar"
-    torch.save(state, filename)
-    if is_best:
-        logging.info("===> Saving current best checkpoint...")
-        shutil.copyfile(filename, filename.replace('pth.tar', 'best.pth.tar'))
+    latest = os.path.join(args.store_root, args.store_name, prefix + "ckpt.pth.tar")
+    torch.save(state, latest)
+    if not is_best:
+        return
+    logging.info("===> Saving current best checkpoint...")
+    shutil.copyfile(latest, latest.replace('pth.tar', 'best.pth.tar'))
 
 
 class _CalibrateFn(torch.autograd.Function):
