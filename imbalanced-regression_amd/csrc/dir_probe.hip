@@ -1,0 +1,108 @@
+// Box calibration probes ("record a measured STREAM-style HBM number and a measured MFMA GEMM peak on the
+// box, and report fractions against both nominal and measured"). Not on the hot path: bench.py times these with HIP events
+// and prints the results next to the nominal peaks of MI355X_MICROARCH.md.
+//   dir_probe_stream_copy : float4 copy, 16 B per lane, grid-stride from 2048 workgroups  -> achievable HBM bytes/s
+//   dir_probe_stream_read : same loads, wave-reduced, one store per workgroup             -> achievable HBM read bytes/s
+//   dir_probe_mfma_bf16   : 8 independent v_mfma_f32_32x32x16_bf16 accumulator chains per wavefront, no memory traffic
+//   dir_probe_mfma_f32    : the same with v_mfma_f32_32x32x2_f32 (the exact-f32 matrix path of the parity mode)
+#include "dir_common.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 pb_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float pb_f32x16;
+
+__global__ void __launch_bounds__(DIR_TPB) probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * DIR_TPB;
+    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(DIR_TPB) probe_read_kernel(const float4* __restrict__ src, float* __restrict__ out, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * DIR_TPB;
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += stride) {
+        const float4 v = src[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, DIR_WAVE);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
+
+template <int CHAINS>
+__global__ void __launch_bounds__(DIR_TPB) probe_mfma_bf16_kernel(int iters, float* __restrict__ out) {
+    pb_f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.0f;
+    pb_bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                      // full-range operands (zero-filled ones clock higher: guide §5.4 rule 25)
+        a[e] = (__bf16)(((int)((threadIdx.x * 37u + e * 11u) & 63u) - 32) * 0.03125f);
+        b[e] = (__bf16)(((int)((threadIdx.x * 53u + e * 7u + blockIdx.x) & 63u) - 32) * 0.03125f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[c][e];
+    out[(size_t)blockIdx.x * DIR_TPB + threadIdx.x] = s;
+}
+
+template <int CHAINS>
+__global__ void __launch_bounds__(DIR_TPB) probe_mfma_f32_kernel(int iters, float* __restrict__ out) {
+    pb_f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.0f;
+    const float a = ((int)((threadIdx.x * 37u) & 63u) - 32) * 0.03125f;
+    const float b = ((int)((threadIdx.x * 53u + blockIdx.x) & 63u) - 32) * 0.03125f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[c][e];
+    out[(size_t)blockIdx.x * DIR_TPB + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!src || !dst || bytes < 16 || (bytes & 15) || !dir_aligned16(src) || !dir_aligned16(dst), DIR_EINVAL);
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src),
+                       static_cast<float4*>(dst), bytes / 16);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_probe_stream_read(const void* src, float* out /* >= 8192 floats */, size_t bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!src || !out || bytes < 16 || (bytes & 15) || !dir_aligned16(src), DIR_EINVAL);
+    hipLaunchKernelGGL(probe_read_kernel, dim3(2048), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src), out, bytes / 16);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// Returns the FLOPs the launch executes through *flops (host); out: >= workgroups * 256 floats.
+extern "C" int dir_probe_mfma_bf16(int workgroups, int iters, float* out, double* flops, dir_stream_t stream) {
+    DIR_RETURN_IF(workgroups <= 0 || iters <= 0 || !out, DIR_EINVAL);
+    hipLaunchKernelGGL((probe_mfma_bf16_kernel<8>), dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), iters, out);
+    DIR_LAUNCH_CHECK();
+    if (flops) *flops = (double)workgroups * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
+    return DIR_OK;
+}
+
+extern "C" int dir_probe_mfma_f32(int workgroups, int iters, float* out, double* flops, dir_stream_t stream) {
+    DIR_RETURN_IF(workgroups <= 0 || iters <= 0 || !out, DIR_EINVAL);
+    hipLaunchKernelGGL((probe_mfma_f32_kernel<4>), dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), iters, out);
+    DIR_LAUNCH_CHECK();
+    if (flops) *flops = (double)workgroups * 4.0 * iters * 4.0 * (2.0 * 32 * 32 * 2);
+    return DIR_OK;
+}

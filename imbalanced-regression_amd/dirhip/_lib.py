@@ -84,6 +84,19 @@ SIGNATURES = {
     "dir_fds_fill_empty_buckets": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_fds_prepare_scale_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),
     "dir_fds_bin_scaled": (c_int, [c_void_p, ctypes.c_longlong, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "dir_conv_f32_fwd": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "dir_conv_f32_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "dir_conv_f32_dgrad_fused": (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
+    "dir_conv_f32_wgrad_workspace": (c_size_t, [c_int] * 9),
+    "dir_conv_f32_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "dir_maxpool3x3s2_f32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_maxpool3x3s2_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_avgpool_f32_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dir_avgpool_f32_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dir_probe_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_probe_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_probe_mfma_bf16": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dir_probe_mfma_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
@@ -128,7 +141,14 @@ def check(rc, what):
 
 
 def stream_ptr(device=None):
-    """Raw hipStream_t of torch's current stream (kernels are enqueued where torch's work is)."""
+    """Raw hipStream_t of torch's current stream (kernels are enqueued where torch's work is). The C-ABI launches on the
+    CURRENT device: tensors that live on another GPU are refused here instead of being launched on the wrong one
+    (one process per GPU is the design; wrap foreign-device work in ``torch.cuda.device(t.device)``)."""
+    if device is not None:
+        idx = device.index if isinstance(device, torch.device) else int(device)
+        if idx is not None and idx != torch.cuda.current_device():
+            raise DirHipError(f"tensors on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                              f"call torch.cuda.set_device / use torch.cuda.device(...) around the call")
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -13,8 +13,18 @@ import torch
 from . import _lib as L
 
 
-def supported(cin, cout):
-    return cin % 64 == 0 and cout % 64 == 0
+def supported(cin, cout, x=None):
+    """Does the bf16 MFMA implicit GEMM take this layer? Channel counts must be multiples of 64 and — when the input
+    ``x`` [N, C, H, W] is given — every tensor of the layer's forward / data-gradient launches must stay inside the
+    kernel's 32-bit byte offsets (``dir_conv_fwd``: N*H*W*C < 2^30 elements, N*H*W < 2^24 rows; reached at a per-GPU
+    batch of ~1300 at 224 px). Anything else runs on the float32 kernels of ``conv_f32``."""
+    if cin % 64 or cout % 64:
+        return False
+    if x is not None:
+        rows = x.shape[0] * x.shape[2] * x.shape[3]
+        if rows >= (1 << 24) or rows * max(cin, cout) >= (1 << 30):
+            return False
+    return True
 
 
 def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None):
@@ -79,7 +89,9 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
 class _ConvFn(torch.autograd.Function):
     """Forward = hand-written MFMA implicit GEMM (+ BatchNorm partial statistics in the epilogue); data gradient of
     stride-1 layers = the same kernel on dY with rotated/transposed weights; weight gradient = the MFMA split-K
-    kernel ``dir_conv_wgrad``. Only the data gradient of the six stride-2 layers still uses the library kernel."""
+    kernel ``dir_conv_wgrad``; 3x3 stride-2 data gradients = four stride-1 launches by output-pixel parity class
+    (``dir_conv_dgrad_s2``); the stride-2 1x1 data gradients live in ``_ProjectionPairFn``. Shapes none of these take
+    (odd-sized maps) use the general float32 data gradient of ``conv_f32`` — never a library kernel."""
 
     @staticmethod
     def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input):
@@ -131,10 +143,12 @@ class _ConvFn(torch.autograd.Function):
             L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
                                               L.stream_ptr(x.device)), "dir_conv_dgrad_s2")
             need_dx = False
-        if need_dx:                                                              # other strided data gradients: library kernel
-            dx = torch.ops.aten.convolution_backward(
-                dy, x, w16, None, [ctx.stride, ctx.stride], [ctx.padding, ctx.padding], [1, 1], False, [0, 0], 1,
-                [True, False, False])[0]
+        if need_dx:
+            # strided data gradients the bf16 kernels do not take (odd-sized maps, a stride-2 1x1 outside a projection
+            # pair): the general float32 MFMA data gradient, on the bf16 weights
+            from .conv_f32 import conv2d_f32_dgrad
+            dx = conv2d_f32_dgrad(dy.float(), w16.float().contiguous(memory_format=torch.channels_last), x.shape[2:],
+                                  ctx.stride, ctx.padding).to(torch.bfloat16)
         if dalias is not None:                                                   # strided layer: eager accumulation
             dx = dalias if dx is None else dx + dalias
         return dx, dw, None, None, None, None, None, None, None
@@ -201,11 +215,6 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_hook(invalidate_weight_cache)
 
 
-import os as _os
-_S2_DGRAD = "s2_dgrad" not in _os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")
-_STEM_WGRAD = "stem_wgrad" not in _os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")
-
-
 class _PreparedWeights:
     """bf16 operands of one conv layer (persistent buffers) + the key of the master weight they were made from."""
     __slots__ = ("key", "w16", "w16_rot", "conv_ref", "shape", "rot_mode")
@@ -218,7 +227,7 @@ class _PreparedWeights:
         self.w16 = torch.empty((cout, cin, r, s), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
         self.w16_rot = None
         self.rot_mode = 0
-        if conv.stride[0] == 2 and (r, s) == (3, 3) and conv.padding[0] == 1 and supported(cout, cin) and _S2_DGRAD:
+        if conv.stride[0] == 2 and (r, s) == (3, 3) and conv.padding[0] == 1 and supported(cout, cin):
             # the four parity-class weights of the stride-2 data gradient, packed (dir_conv_dgrad_s2)
             self.w16_rot = torch.empty(cin * 9 * cout, dtype=torch.bfloat16, device=w.device)
             self.rot_mode = 1
@@ -297,6 +306,17 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     forward and the backward share it), and all layers of a network are re-cast by one launch. The operands live in
     persistent buffers that are rewritten in place: a backward pass must run before the optimizer step that follows
     its forward pass (as in any training loop)."""
+    if x.dtype == torch.float32:
+        # float32 parity mode: the same node contract on the exact-float32 kernels (statistics are then computed by the
+        # BatchNorm node itself)
+        from .conv_f32 import conv_graph_f32
+        grad_mode = torch.is_grad_enabled()
+        aliasing = bool(alias_input and grad_mode and x.requires_grad)
+        relu_input = bool(relu_flag is not None and aliasing and conv.stride[0] == 1 and not relu_flag[0])
+        if relu_input:
+            relu_flag[0] = True
+        y, alias = conv_graph_f32(x, conv, aliasing, relu_input)
+        return (y, None, alias if alias is not None else x) if alias_input else (y, None)
     w = conv.weight
     w16, w16_rot = _prepared(conv)
     if x.dtype != torch.bfloat16:
@@ -320,6 +340,13 @@ def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
     """``conv1(x)`` and ``conv_d(x)`` (both 1x1, bias-free, padding 0; ``conv1`` stride 1) as one node — see
     ``_ProjectionPairFn``. Returns ``(y1, stats1, yd, statsd)``. ``relu_flag``: as in ``conv_bn_input`` (x is only
     used here, so the flag can always be claimed when gradients flow)."""
+    if x.dtype == torch.float32:
+        from .conv_f32 import projection_pair_f32
+        relu_input = bool(relu_flag is not None and torch.is_grad_enabled() and x.requires_grad and not relu_flag[0])
+        if relu_input:
+            relu_flag[0] = True
+        y1, yd = projection_pair_f32(x, conv1, conv_d, relu_input)
+        return y1, None, yd, None
     w1_16, w1_rot = _prepared(conv1)
     wd_16, wd_rot = _prepared(conv_d)
     assert w1_rot is not None and wd_rot is not None
@@ -334,10 +361,10 @@ def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
                                    relu_input)
 
 
-def projection_pair_ok(conv1, conv_d):
+def projection_pair_ok(conv1, conv_d, x=None):
     def one(c, strides):
         return (c.kernel_size == (1, 1) and c.padding == (0, 0) and c.stride[0] in strides and c.stride[0] == c.stride[1]
-                and c.bias is None and c.groups == 1 and supported(c.in_channels, c.out_channels))
+                and c.bias is None and c.groups == 1 and supported(c.in_channels, c.out_channels, x))
     return one(conv1, (1,)) and one(conv_d, (1, 2))
 
 
@@ -367,15 +394,10 @@ class _StemConvFn(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         n, _, h, w = x16.shape
-        if _STEM_WGRAD:
-            dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x16.device, memory_format=torch.channels_last)
-            ws = torch.empty(L.lib().dir_stem_conv_wgrad_workspace(n, h), dtype=torch.uint8, device=x16.device)
-            L.check(L.lib().dir_stem_conv_wgrad(L.ptr(dy), L.ptr(x16), L.ptr(dw), n, h, w, L.ptr(ws), ws.numel(),
-                                                L.stream_ptr(x16.device)), "dir_stem_conv_wgrad")
-        else:
-            w16 = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(dy, x16, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x16.device, memory_format=torch.channels_last)
+        ws = torch.empty(L.lib().dir_stem_conv_wgrad_workspace(n, h), dtype=torch.uint8, device=x16.device)
+        L.check(L.lib().dir_stem_conv_wgrad(L.ptr(dy), L.ptr(x16), L.ptr(dw), n, h, w, L.ptr(ws), ws.numel(),
+                                            L.stream_ptr(x16.device)), "dir_stem_conv_wgrad")
         return None, dw.to(weight.dtype), None, None
 
 

@@ -94,7 +94,9 @@ class SyntheticAgeDataset(data.Dataset):
         w = np.float32(1.) if self.weights is None else self.weights[index]
         return img, np.asarray([self.labels[index]], dtype=np.float32), np.asarray([w], dtype=np.float32)
 
-    def device_batches(self, indices, batch_size, device, channels_last=True, seed=0):
+    def device_batches(self, indices, batch_size, device, channels_last=True, seed=0, valid=None):
+        """Yields ``(x, y, w)`` device batches — ``(x, y, w, valid)`` with the host bool slice when ``valid`` (the padding
+        mask of ``parallel.shard_indices``) is given."""
         w_all = None if self.weights is None else torch.as_tensor(np.asarray(self.weights, dtype=np.float32))
         lab_all = torch.as_tensor(self.labels)
         g = torch.Generator(device=device).manual_seed(self.seed * 7919 + seed)
@@ -105,4 +107,4 @@ class SyntheticAgeDataset(data.Dataset):
                 x = x.contiguous(memory_format=torch.channels_last)
             y = lab_all[idx].to(device).view(-1, 1)
             w = torch.ones_like(y) if w_all is None else w_all[idx].to(device).view(-1, 1)
-            yield x, y, w
+            yield (x, y, w) if valid is None else (x, y, w, valid[s:s + batch_size])

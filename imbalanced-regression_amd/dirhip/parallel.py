@@ -163,15 +163,21 @@ class DataParallelEngine(nn.Module):
         self._callback_queued = False
 
 
-def shard_indices(n, rank, world, epoch_seed=None):
+def shard_indices(n, rank, world, epoch_seed=None, with_valid=False):
     """Indices of this rank's shard of an n-sample epoch (shuffled identically on every rank when a seed is
-    given; padded by wrap-around so every rank runs the same number of steps)."""
+    given; padded by wrap-around so every rank runs the same number of steps). ``with_valid=True`` also returns a bool
+    mask that is False at the padded (duplicated) positions: they are trained on like any sample (as with a
+    DistributedSampler) but must not enter the FDS epoch statistics, which are statistics of the dataset."""
     if epoch_seed is None:
         order = torch.arange(n)
     else:
         order = torch.randperm(n, generator=torch.Generator().manual_seed(int(epoch_seed)))
     per = (n + world - 1) // world
     pad = per * world - n
+    valid = torch.ones(n + pad, dtype=torch.bool)
     if pad:
         order = torch.cat([order, order[:pad]])
+        valid[n:] = False
+    if with_valid:
+        return order[rank::world], valid[rank::world]
     return order[rank::world]

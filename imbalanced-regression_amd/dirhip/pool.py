@@ -1,6 +1,8 @@
-"""3x3 / stride-2 / pad-1 max pooling for bf16 channels_last activations (``dir_maxpool3x3s2_*``): forward keeps one
-argmax byte per element, backward gathers (no atomics). Replaces ``nn.MaxPool2d(3, 2, 1)`` of ``resnet.py:82`` on the
-bf16 path; other dtypes / geometries keep using the module."""
+"""Pools of the ResNet stack (``resnet.py:82,85,131,136-137``) on hand-written kernels: 3x3 / stride-2 / pad-1 max pooling
+(one argmax byte per element forward, atomic-free gather backward), the global average pool, and the fused stem tail
+``maxpool(relu(bn(x)))``. bf16 channels_last activations use ``dir_maxpool3x3s2_*`` / ``dir_avgpool_*`` /
+``dir_bn_relu_maxpool_*``; float32 activations (parity mode) use the ``*_f32_*`` kernels of ``conv_f32``. Geometries the
+reference's ResNet never uses raise instead of silently falling back to a library kernel."""
 import torch
 
 from . import _lib as L
@@ -34,10 +36,18 @@ class _MaxPoolFn(torch.autograd.Function):
 
 
 def maxpool3x3s2(x, module):
-    """``module`` = the registered nn.MaxPool2d (used for anything that is not bf16 CUDA 3x3/s2/p1)."""
-    ok = (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and module.kernel_size in (3, (3, 3))
-          and module.stride in (2, (2, 2)) and module.padding in (1, (1, 1)) and not module.ceil_mode)
-    return _MaxPoolFn.apply(x) if ok else module(x)
+    """``module(x)`` for the registered ``nn.MaxPool2d(3, 2, 1)`` on a channels_last device tensor."""
+    geom = (module.kernel_size in (3, (3, 3)) and module.stride in (2, (2, 2)) and module.padding in (1, (1, 1))
+            and module.dilation in (1, (1, 1)) and not module.ceil_mode)
+    if not x.is_cuda:
+        raise L.DirHipError(f"maxpool: input on {x.device}; the pools run only as HIP kernels (no CPU fallback)")
+    if not geom:
+        raise L.DirHipError(f"maxpool: only MaxPool2d(3, 2, 1) is implemented, got {module}")
+    if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
+        return _MaxPoolFn.apply(x)
+    from .conv_f32 import maxpool3x3s2_f32
+    y = maxpool3x3s2_f32(x.float())
+    return y if x.dtype == torch.float32 else y.to(x.dtype)
 
 
 class _GlobalAvgPoolFn(torch.autograd.Function):
@@ -62,15 +72,18 @@ class _GlobalAvgPoolFn(torch.autograd.Function):
 
 
 def global_avgpool_flat(x, module):
-    """``module(x).view(N, -1)`` of ``resnet.py:136-137`` (``module`` = the registered nn.AvgPool2d). When the pool
-    window is the whole bf16 CUDA map the mean is formed by ``dir_avgpool_fwd`` and returned as float32 ``[N, C]``;
-    anything else uses the module."""
+    """``module(x).view(N, -1)`` of ``resnet.py:136-137`` (``module`` = the registered nn.AvgPool2d(7)) as float32
+    ``[N, C]``: the pool window must be the whole map (it is, for the reference's 224-px inputs)."""
     k = module.kernel_size if isinstance(module.kernel_size, tuple) else (module.kernel_size, module.kernel_size)
-    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and tuple(x.shape[2:]) == tuple(k) and x.shape[1] % 8 == 0
-            and module.padding in (0, (0, 0))):
+    if not x.is_cuda:
+        raise L.DirHipError(f"avgpool: input on {x.device}; the pools run only as HIP kernels (no CPU fallback)")
+    if x.dim() != 4 or tuple(x.shape[2:]) != tuple(k) or module.padding not in (0, (0, 0)):
+        raise L.DirHipError(f"avgpool: only the global pool (window = whole {tuple(k)} map) is implemented, got a "
+                            f"{tuple(x.shape[2:])} map — the reference's network needs img_size 224")
+    if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0:
         return _GlobalAvgPoolFn.apply(x)
-    y = module(x)
-    return y.view(y.size(0), -1)
+    from .conv_f32 import global_avgpool_flat_f32
+    return global_avgpool_flat_f32(x.float())
 
 
 class _BnReluMaxPoolFn(torch.autograd.Function):

@@ -6,40 +6,64 @@ reference checkpoints load), same initialisation stream, same forward contract
 (``(pred, encoding)`` when training with FDS, else ``pred``; the returned ``encoding`` is the tensor
 ``FDS.smooth`` calibrated in place — SURVEY A.2).
 
-Backbone (bf16, channels_last, under ``dirhip.parallel.DataParallelEngine``'s autocast): every convolution with
-Cin, Cout % 64 == 0 is the hand-written MFMA implicit GEMM (``dirhip.conv`` -> ``dir_conv_*``: forward, stride-1 data
-gradient, weight gradient; BatchNorm statistics in its epilogue); the 7x7 stem and the six stride-2 data gradients use
-the library. Every BatchNorm (+ residual add) (+ ReLU) is ONE fused hand-written HIP node (``dirhip.bn.bn_act`` ->
-``dir_bn_*``); the pool -> FDS calibrate -> linear -> weighted-loss tail is the hand-written HIP path and always fp32.
-GPU only (no CPU fallback).
+Backbone, bf16 product path (channels_last, under ``dirhip.parallel.DataParallelEngine``'s autocast): the 7x7 stem
+(``dir_stem_conv_*``), every other convolution as the hand-written MFMA implicit GEMM (``dirhip.conv`` -> ``dir_conv_*``:
+forward, stride-1 / stride-2 data gradients, weight gradient; BatchNorm statistics in the epilogue), every BatchNorm
+(+ residual add) (+ ReLU) as ONE fused HIP node (``dirhip.bn`` -> ``dir_bn_*``), fused stem tail and pools
+(``dirhip.pool``). Parity mode (no autocast, float32 activations): the SAME graph with the exact-float32 MFMA convolutions
+and pools of ``dirhip.conv_f32`` (``dir_conv_f32_*``) in place of the bf16 ones. No library convolution, BatchNorm or
+pooling call exists on either path; shapes the bf16 kernels do not take fall back to the float32 kernels, never to a library.
+The pool -> FDS calibrate -> linear -> weighted-loss tail is hand-written HIP and always fp32. GPU only (no CPU fallback).
 """
 import logging
 import math
-import os
 
 import torch
 import torch.nn as nn
 
 from .bn import BatchCounters, bn_act, bn_join
 from .conv import conv_bn_input, projection_pair, projection_pair_ok, stem_conv, stem_conv_ok, supported as _igemm_ok
+from .conv_f32 import conv_f32, conv_ok
 from .fds import FDS
 from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
 
 print = logging.info
 
-# A/B switches for measurements (comma separated): "proj_alias" = eager gradient add at projection-shortcut blocks,
-# "relu_defer" = ReLU backward inside the BatchNorm node instead of the next block's data-gradient kernel
-_DISABLED = set(filter(None, os.environ.get("DIR_DISABLE_FUSIONS", "").split(",")))
+# The fused wiring of a bottleneck block (shared block-input gradient accumulation inside conv1's data-gradient kernel,
+# ReLU backward of relu(bn3 + shortcut) deferred into the consumer, projection pair, two-BatchNorm join) is ONE graph for
+# both activation dtypes. ``set_graph_fusion(False)`` builds the plain composition of the very same kernels instead
+# (conv -> BatchNorm(+residual)(+ReLU) nodes, autograd's own gradient accumulation): the tests use it as the oracle for
+# the fusion wiring — both graphs must produce the same forward bit for bit and the same gradients.
+_FUSED_GRAPH = [True]
+
+
+def set_graph_fusion(enabled):
+    """Returns the previous setting."""
+    prev = _FUSED_GRAPH[0]
+    _FUSED_GRAPH[0] = bool(enabled)
+    return prev
+
+
+def _fusable(x):
+    return _FUSED_GRAPH[0] and x.dtype in (torch.bfloat16, torch.float32)
+
+
+def _own_conv(x, conv):
+    """Does this layer run as a graph node of ``dirhip.conv`` (bf16 MFMA kernels, or their float32 twins in parity mode)?"""
+    if x.dtype == torch.float32:
+        return conv_ok(conv)
+    return x.dtype == torch.bfloat16 and _igemm_ok(conv.in_channels, conv.out_channels, x)
 
 
 def _conv_bn(x, conv, bn, relu, residual=None, defer_relu_grad=False):
     """conv -> BatchNorm (+ residual) (+ ReLU). bf16 activations: hand-written MFMA implicit-GEMM convolution whose
-    epilogue already produced the BatchNorm statistics, then ONE fused normalise/add/ReLU pass. fp32 activations
-    (parity mode): library convolution + the fused HIP BatchNorm node."""
-    if x.dtype == torch.bfloat16 and _igemm_ok(conv.in_channels, conv.out_channels):
+    epilogue already produced the BatchNorm statistics, then ONE fused normalise/add/ReLU pass. float32 activations
+    (parity mode): the exact-float32 MFMA convolution + the same fused BatchNorm node. bf16 layers whose channel counts
+    the MFMA kernel does not take are computed by the float32 kernels (casts around them)."""
+    if _own_conv(x, conv):
         y, partial = conv_bn_input(x, conv, want_stats=bn.training)
         return bn_act(y, bn, relu=relu, residual=residual, partial=partial, defer_relu_grad=defer_relu_grad)
-    return bn_act(conv(x), bn, relu=relu, residual=residual)
+    return bn_act(conv_f32(x, conv), bn, relu=relu, residual=residual)
 
 
 class Bottleneck(nn.Module):
@@ -60,8 +84,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if x.dtype == torch.bfloat16 and self.downsample is not None and "proj_pair" not in _DISABLED and self.bn3.training \
-                and self.downsample[1].training and projection_pair_ok(self.conv1, self.downsample[0]) \
+        fused = _fusable(x)
+        if fused and self.downsample is not None and self.bn3.training and self.downsample[1].training \
+                and projection_pair_ok(self.conv1, self.downsample[0], x) \
                 and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) and (x.shape[2] | x.shape[3]) % 2 == 0:
             # projection block: conv1 and the downsample conv are one node (their data gradients and the previous
             # block's ReLU backward meet inside one kernel, the stride-2 gradient in compact form), and
@@ -71,10 +96,8 @@ class Bottleneck(nn.Module):
             y = bn_act(y, self.bn1, relu=True, partial=partial)
             y = _conv_bn(y, self.conv2, self.bn2, relu=True)
             y3, partial3 = conv_bn_input(y, self.conv3, want_stats=True)
-            return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True,
-                           defer_relu_grad="relu_defer" not in _DISABLED)
-        if x.dtype == torch.bfloat16 and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels) and \
-                (self.downsample is None or "proj_alias" not in _DISABLED):
+            return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True, defer_relu_grad=True)
+        if fused and _own_conv(x, self.conv1) and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels, x):
             # conv1's node also hands back the block input, and the shortcut branch (identity or projection) reads THAT:
             # the two gradients that meet at the block input are then summed inside conv1's data-gradient kernel
             # (its `addend`) instead of by an eager add kernel
@@ -82,23 +105,13 @@ class Bottleneck(nn.Module):
             y, partial, xin = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True,
                                             relu_flag=getattr(x, "_dir_relu_flag", None))
             y = bn_act(y, self.bn1, relu=True, partial=partial)
-            if self.downsample is not None and self.bn3.training and self.downsample[1].training and "bn_join" not in _DISABLED \
-                    and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) \
-                    and _igemm_ok(self.downsample[0].in_channels, self.downsample[0].out_channels):
-                # projection block: relu(bn3(conv3(.)) + bn_d(conv_d(x))) with both normalisations in ONE apply pass
-                # (bn_d's output is never materialised)
-                r, partial_r = conv_bn_input(xin, self.downsample[0], want_stats=True)
-                y = _conv_bn(y, self.conv2, self.bn2, relu=True)
-                y3, partial3 = conv_bn_input(y, self.conv3, want_stats=True)
-                return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True,
-                               defer_relu_grad="relu_defer" not in _DISABLED)
             shortcut = xin if self.downsample is None else _conv_bn(xin, self.downsample[0], self.downsample[1], relu=False)
         else:
             shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
             y = _conv_bn(x, self.conv1, self.bn1, relu=True)
         y = _conv_bn(y, self.conv2, self.bn2, relu=True)
         # relu(bn3(conv3(.)) + shortcut); the next block's conv1 may take over the ReLU backward of this node
-        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut, defer_relu_grad="relu_defer" not in _DISABLED)
+        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut, defer_relu_grad=fused)
 
 
 class ResNet(nn.Module):
@@ -154,15 +167,14 @@ class ResNet(nn.Module):
     def features(self, x):
         """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
         partial = None
-        if "stem_conv" not in _DISABLED and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
-                and stem_conv_ok(x, self.conv1):
+        amp_bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if amp_bf16 and stem_conv_ok(x, self.conv1):
             x, partial = stem_conv(x, self.conv1, want_stats=self.bn1.training)   # hand-written MFMA stem, statistics in its epilogue
         else:
-            x = self.conv1(x)
-        if "stem_tail" in _DISABLED:
-            x = maxpool3x3s2(bn_act(x, self.bn1, relu=True, partial=partial), self.maxpool)
-        else:
-            x = bn_relu_maxpool(x, self.bn1, self.maxpool, partial=partial)
+            x = conv_f32(x, self.conv1)                   # parity mode (float32) / image widths the bf16 stem does not take
+            if amp_bf16:
+                x = x.to(torch.bfloat16)
+        x = bn_relu_maxpool(x, self.bn1, self.maxpool, partial=partial)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return global_avgpool_flat(x, self.avgpool)
 

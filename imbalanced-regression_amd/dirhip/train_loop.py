@@ -60,13 +60,21 @@ class EpochFeatures:
 
 @torch.no_grad()
 def epoch_tail(model, batches, epoch, store):
-    """``batches`` yields (inputs, targets) already on the device. ``model`` is the (possibly wrapped)
-    network in train mode (BN uses batch statistics, like the reference's second pass — SURVEY A.2)."""
+    """``batches`` yields ``(inputs, targets)`` or ``(inputs, targets, valid)`` already on the device (``valid``: HOST bool
+    ``[B]``, False for rows that only pad a data-parallel shard — they run through the network with their batch but are
+    left out of the statistics). ``model`` is the (possibly wrapped) network in train mode (BN uses batch statistics,
+    like the reference's second pass — SURVEY A.2)."""
     fds_mod = model.module.FDS if hasattr(model, "module") else model.FDS
     store.reset()
-    for inputs, targets in batches:
+    for batch in batches:
+        inputs, targets = batch[0], batch[1]
+        valid = batch[2] if len(batch) > 2 else None
         _, feature = model(inputs, targets, epoch)
-        store.append(feature, targets)
+        if valid is not None and not bool(valid.all()):          # `valid` is a host tensor: no device sync for full batches
+            keep = valid.to(feature.device)
+            feature, targets = feature[keep], targets[keep]
+        if feature.shape[0]:
+            store.append(feature, targets)
     feats, labels = store.view()
     fds_mod.update_last_epoch_stats(epoch)
     fds_mod.update_running_stats(feats, labels, epoch)

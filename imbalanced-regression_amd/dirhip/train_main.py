@@ -84,6 +84,8 @@ def build_parser(dataset_default='imdb_wiki'):
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic samples (no image files)')
     p.add_argument('--amp', type=str, default='bf16', choices=['bf16', 'fp32'], help='conv-stack precision')
     p.add_argument('--max_steps', type=int, default=0, help='truncate every epoch to this many steps (0 = full)')
+    p.add_argument('--overwrite', action='store_true', help='delete an existing run folder of the same name (the reference asks on '
+                   'the terminal; without a terminal nothing is deleted unless this flag is given)')
     p.set_defaults(augment=True)
     return p
 
@@ -113,13 +115,33 @@ class _NullTB:
 
 
 def _loader_batches(loader, device):
-    for inputs, targets, weights in loader:
-        yield (inputs.to(device, non_blocking=True), targets.to(device, non_blocking=True),
-               weights.to(device, non_blocking=True))
+    for batch in loader:
+        inputs, targets, weights = batch[0], batch[1], batch[2]
+        out = (inputs.to(device, non_blocking=True), targets.to(device, non_blocking=True), weights.to(device, non_blocking=True))
+        yield out + ((batch[3].bool(),) if len(batch) > 3 else ())
+
+
+class _ShardSubset(torch.utils.data.Dataset):
+    """This rank's shard of a dataset; every item also carries whether it is a real sample of the epoch or one of the
+    wrap-around duplicates that pad the shard (``parallel.shard_indices``)."""
+
+    def __init__(self, dataset, indices, valid):
+        self.dataset, self.indices, self.valid = dataset, indices, valid
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        return tuple(self.dataset[self.indices[i]]) + (bool(self.valid[i]),)
+
+
+def _check_loss(v):
+    assert not (np.isnan(v) or v > 1e6), f"Loss explosion: {v}"
+    return v
 
 
 def train(train_batches, n_steps, model, optimizer, epoch, args, store):
-    """train.py:234-283. ``train_batches()`` returns a fresh iterator of device (inputs, targets, weights)."""
+    """train.py:234-283. ``train_batches()`` returns a fresh iterator of device (inputs, targets, weights[, valid])."""
     batch_time = AverageMeter('Time', ':6.2f')
     losses = AverageMeter(f'Loss ({args.loss.upper()})', ':.3f')
     progress = ProgressMeter(n_steps, [batch_time, losses], prefix="Epoch: [{}]".format(epoch))
@@ -127,61 +149,63 @@ def train(train_batches, n_steps, model, optimizer, epoch, args, store):
     model.train()
     end = time.time()
     pending = []
-    for idx, (inputs, targets, weights) in enumerate(train_batches()):
+    for idx, batch in enumerate(train_batches()):
+        inputs, targets, weights = batch[0], batch[1], batch[2]
         if args.max_steps and idx >= args.max_steps:
             break
         loss = train_step(model, optimizer, inputs, targets, weights, epoch, loss_fn, fds=args.fds)
         pending.append((loss, inputs.size(0)))
         if idx % args.print_freq == 0 or idx == n_steps - 1:
             for l, n in pending:                       # one host sync per print_freq steps (train.py:256-258 syncs every step)
-                v = l.item()
-                assert not (np.isnan(v) or v > 1e6), f"Loss explosion: {v}"
-                losses.update(v, n)
+                losses.update(_check_loss(l.item()), n)
             pending = []
             batch_time.update(time.time() - end)
             end = time.time()
             progress.display(idx)
     for l, n in pending:
-        losses.update(l.item(), n)
+        losses.update(_check_loss(l.item()), n)
 
     if args.fds and epoch >= args.start_update:
         print(f"Create Epoch [{epoch}] features of all training data...")
 
         def tail_batches():
-            for i, (inputs, targets, _) in enumerate(train_batches()):
+            for i, batch in enumerate(train_batches()):
                 if args.max_steps and i >= args.max_steps:
                     break
-                yield inputs, targets
+                yield (batch[0], batch[1]) + ((batch[3],) if len(batch) > 3 else ())
         epoch_tail(model, tail_batches(), epoch, store)
     return losses.avg
 
 
 def validate(val_batches, n_batches, model, args, train_labels=None, prefix='Val'):
-    """train.py:286-335."""
+    """train.py:286-335. Same numbers as the reference: per-batch float32 MSE / L1 means averaged with the batch sizes as
+    weights (``AverageMeter``), G-Mean of all absolute errors, per-shot metrics — but the per-batch values are read back
+    once at the end instead of with two ``.item()`` host syncs per batch."""
     losses_mse = AverageMeter('Loss (MSE)', ':.3f')
     losses_l1 = AverageMeter('Loss (L1)', ':.3f')
     progress = ProgressMeter(n_batches, [losses_mse, losses_l1], prefix=f'{prefix}: ')
     model.eval()
-    preds, labels = [], []
+    preds, labels, per_batch = [], [], []
     with torch.no_grad():
         for idx, (inputs, targets, _) in enumerate(val_batches()):
             outputs = model(inputs).float()
             preds.append(outputs)
             labels.append(targets)
-            if idx % args.print_freq == 0:
-                losses_mse.update(nn.functional.mse_loss(outputs, targets).item(), inputs.size(0))
-                losses_l1.update(nn.functional.l1_loss(outputs, targets).item(), inputs.size(0))
-                progress.display(idx)
+            per_batch.append((nn.functional.mse_loss(outputs, targets), nn.functional.l1_loss(outputs, targets), inputs.size(0)))
+    for i, (m, l, n) in enumerate(per_batch):
+        losses_mse.update(m.item(), n)
+        losses_l1.update(l.item(), n)
+        if i % args.print_freq == 0:
+            progress.display(i)
     preds = torch.cat(preds).cpu().numpy()
     labels = torch.cat(labels).cpu().numpy()
     err = np.abs(preds - labels)
-    mse, l1 = float(np.mean((preds - labels) ** 2)), float(np.mean(err))
     shot_dict = shot_metrics(np.hstack(preds), np.hstack(labels), train_labels)
     loss_gmean = gmean(np.hstack(err), axis=None).astype(float)
-    print(f" * Overall: MSE {mse:.3f}\tL1 {l1:.3f}\tG-Mean {loss_gmean:.3f}")
+    print(f" * Overall: MSE {losses_mse.avg:.3f}\tL1 {losses_l1.avg:.3f}\tG-Mean {loss_gmean:.3f}")
     for shot, title in (('many', 'Many'), ('median', 'Median'), ('low', 'Low')):
         print(f" * {title}: MSE {shot_dict[shot]['mse']:.3f}\tL1 {shot_dict[shot]['l1']:.3f}\tG-Mean {shot_dict[shot]['gmean']:.3f}")
-    return mse, l1, loss_gmean
+    return losses_mse.avg, losses_l1.avg, loss_gmean
 
 
 def shot_metrics(preds, labels, train_labels, many_shot_thr=100, low_shot_thr=20):
@@ -252,8 +276,8 @@ def run(argv=None, dataset_default='imdb_wiki'):
         n_train = len(train_set)
 
         def train_batches(epoch):
-            idx = shard_indices(n_train, rank, world, epoch_seed=epoch)
-            return lambda: train_set.device_batches(idx, args.batch_size, device, seed=epoch)
+            idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
+            return lambda: train_set.device_batches(idx, args.batch_size, device, seed=epoch, valid=valid)
 
         def eval_batches(ds):
             return lambda: ds.device_batches(torch.arange(len(ds)), args.batch_size, device)
@@ -261,7 +285,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
         n_val = (len(val_set) + args.batch_size - 1) // args.batch_size
     else:
         import pandas as pd
-        from torch.utils.data import DataLoader, Subset
+        from torch.utils.data import DataLoader
         print(f"File (.csv): {args.dataset}.csv")
         df = pd.read_csv(os.path.join(args.data_dir, f"{args.dataset}.csv"))
         df_train, df_val, df_test = df[df['split'] == 'train'], df[df['split'] == 'val'], df[df['split'] == 'test']
@@ -274,8 +298,8 @@ def run(argv=None, dataset_default='imdb_wiki'):
         n_train = len(train_set)
 
         def train_batches(epoch):
-            idx = shard_indices(n_train, rank, world, epoch_seed=epoch).tolist()
-            loader = DataLoader(Subset(train_set, idx), batch_size=args.batch_size, shuffle=True,
+            idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
+            loader = DataLoader(_ShardSubset(train_set, idx.tolist(), valid.tolist()), batch_size=args.batch_size, shuffle=True,
                                 num_workers=args.workers, pin_memory=True, drop_last=False)
             return lambda: _loader_batches(loader, device)
 

@@ -51,10 +51,11 @@ class ProgressMeter(object):
 
 
 def query_yes_no(question):
-    """utils.py:51-64. Non-interactive sessions (no tty) answer yes instead of blocking on input()."""
+    """utils.py:51-64: ask on the terminal. Without a terminal (torchrun, batch jobs) nobody can answer, and the
+    question guards an ``rmtree``: the answer is then NO — the caller must opt in explicitly (``--overwrite``)."""
     import sys
     if not sys.stdin or not sys.stdin.isatty():
-        return True
+        return False
     answers = {"yes": True, "y": True, "ye": True, "no": False, "n": False}
     while True:
         print(question + " [Y/n] ", end=':')
@@ -67,14 +68,16 @@ def query_yes_no(question):
 
 
 def prepare_folders(args):
-    """utils.py:67-78."""
+    """utils.py:67-78. An existing run folder (with its checkpoints) is deleted only on an explicit yes: the
+    ``--overwrite`` flag, or the interactive answer when there is a terminal."""
     store = os.path.join(args.store_root, args.store_name)
     if os.path.exists(store) and not args.resume and not args.pretrained and not args.evaluate:
-        if query_yes_no('overwrite previous folder: {} ?'.format(store)):
+        if getattr(args, "overwrite", False) or query_yes_no('overwrite previous folder: {} ?'.format(store)):
             shutil.rmtree(store)
             print(store + ' removed.')
         else:
-            raise RuntimeError('Output folder {} already exists'.format(store))
+            raise RuntimeError('Output folder {} already exists; pass --overwrite to replace it or --resume <ckpt> to '
+                               'continue it'.format(store))
     for folder in (args.store_root, store):
         if not os.path.exists(folder):
             print(f"===> Creating folder: {folder}")

@@ -364,6 +364,51 @@ int dir_fds_prepare_scale_ex(const float* v1, const float* v2, int nb, int C, fl
 int dir_fds_bin_scaled(const float* labels, long long n, float mult, int bucket_start, int bucket_num,
                        int32_t* bins, dir_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Exact-float32 convolutions + pools: the PARITY MODE of the ResNet-50 stack (resnet50 run without autocast) and the
+ * general fallback for shapes the bf16 MFMA kernels do not take (channel counts not multiples of 64, odd-sized strided
+ * data gradients, tensors beyond their 32-bit offset range).  Replace nn.Conv2d forward / autograd for ANY layer of
+ * imdb-wiki-dir/resnet.py:44-49,79,112-116 (cuDNN in the reference) with implicit GEMMs on v_mfma_f32_32x32x2_f32, which
+ * is bit-for-bit a k-ordered fmaf chain (float32 products, float32 accumulation).  No library convolution is called
+ * anywhere in the package.
+ *   x  [N, H, W, Cin]  f32 NHWC        w  [Cout, R, S, Cin] f32 (= a channels_last [Cout, Cin, R, S] tensor)
+ *   y / dy [N, Ho, Wo, Cout] f32 NHWC, Ho = (H + 2 pad - R) / stride + 1
+ *   dir_conv_f32_dgrad: dx [N, H, W, Cin]   (every element written; no zero fill needed)
+ *   dir_conv_f32_wgrad: dw [Cout, R, S, Cin]; deterministic split-K through `workspace`
+ *                       (>= dir_conv_f32_wgrad_workspace(...) bytes, 256-byte aligned). */
+int dir_conv_f32_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                     int stride, int pad, dir_stream_t stream);
+int dir_conv_f32_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
+                       int stride, int pad, dir_stream_t stream);
+/* data gradient with the fused store epilogue of the bf16 path (dir_conv_fwd_fused / dir_conv_dgrad_join): dx = dgrad
+ * (+ addend [N,H,W,Cin]) (+ addend_s2, COMPACT [N,H/2,W/2,Cin], at the even pixels) then zeroed where !(relu_mask > 0);
+ * any of the three may be NULL.  This is what lets the float32 parity mode run the SAME fused autograd graph as the bf16
+ * product path (block-input gradient accumulation, deferred ReLU backward, projection pair). */
+int dir_conv_f32_dgrad_fused(const float* dy, const float* w, const float* addend, const float* addend_s2,
+                             const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
+                             int stride, int pad, dir_stream_t stream);
+size_t dir_conv_f32_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
+                       int stride, int pad, void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* float32 NHWC pools of the parity mode: MaxPool2d(3, 2, 1) with an argmax byte (resnet.py:82,131) and the global
+ * average pool (resnet.py:85,136-137; sequential window sum / HW like torch's AvgPool2d). */
+int dir_maxpool3x3s2_f32_fwd(const float* x, float* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);
+int dir_maxpool3x3s2_f32_bwd(const float* dy, const void* argmax, float* dx, int N, int H, int W, int C, dir_stream_t stream);
+int dir_avgpool_f32_fwd(const float* x, float* y, int N, int HW, int C, dir_stream_t stream);
+int dir_avgpool_f32_bwd(const float* dy, float* dx, int N, int HW, int C, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Box calibration probes (measured STREAM-style HBM number and measured MFMA peak of THIS box, reported
+ * next to the nominal 8 TB/s / 2.5 PFLOP/s).  Not part of the reference's path; bench.py times them with HIP events.
+ *   dir_probe_stream_copy: dst[i] = src[i], 16 B per lane, 2048 workgroups grid-stride  (moves 2 * bytes)
+ *   dir_probe_stream_read: read-only stream, wave-reduced, out >= 8192 floats           (moves bytes)
+ *   dir_probe_mfma_bf16 / _f32: `iters` rounds of independent MFMA chains per wavefront, no memory traffic;
+ *                          *flops (host, nullable) receives the FLOPs of the launch; out >= workgroups * 256 floats. */
+int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, dir_stream_t stream);
+int dir_probe_stream_read(const void* src, float* out, size_t bytes, dir_stream_t stream);
+int dir_probe_mfma_bf16(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
+int dir_probe_mfma_f32(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
