@@ -46,6 +46,7 @@ struct ConvP {
 };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
+constexpr int CV_DMA_MIN_KT = 36;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+14 % from 36 steps up, slower below 16 (profiles/r02_conv_variants.txt)
 constexpr int CV_OOB = (int)0x80000000;                         // buffer-load offset beyond any tensor: the load returns zeros
 
 __device__ __forceinline__ uint32_t cv_f2bf(float f) {
@@ -84,6 +85,108 @@ __device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsign
                     csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
                 }
             }
+}
+
+// Epilogue shared by the K-loop variants: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free: the caller
+// has passed a barrier after its last fragment read) -> 16-B row stores with the fused statistics / addend / mask options.
+template <int BN>
+__device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[(BN == 128) ? 2 : 1][2], unsigned char* smem, int t, int m0,
+                                            int n0, int mt) {
+    constexpr int MI = (BN == 128) ? 2 : 1;
+    constexpr int NI = 2;
+    constexpr int WM = MI * 32;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row (padding: rows r, r+4 on disjoint banks)
+    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
+    float csum[NI], csq[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
+    unsigned char* cbase = Cs + (wm * WM + 4 * fhalf) * CS_STRIDE + (wn * 64 + frow) * 2;
+    if (p.stats) cv_stage_acc<MI, NI, CS_STRIDE, true>(acc, cbase, csum, csq);
+    else cv_stage_acc<MI, NI, CS_STRIDE, false>(acc, cbase, csum, csq);
+    if (p.stats) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
+            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
+            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
+        }
+    }
+    __syncthreads();
+    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
+        const int which = t / BN, col = t - which * BN;
+        float s = 0.0f;
+        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
+        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
+        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
+    }
+    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
+    constexpr int RPI = DIR_TPB / CPR;                          // rows per pass of the workgroup
+    const int srow = t / CPR, sch = t - srow * CPR;
+    const unsigned char* cs = Cs + srow * CS_STRIDE + sch * 16;
+    size_t go = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
+    const size_t gstep = (size_t)RPI * p.Cout;
+    const bool full = m0 + CV_BM <= p.M;
+#pragma unroll
+    for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
+        if (full || m0 + srow + i * RPI < p.M) {
+            uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+            if (p.o2) {                                         // parity class of a stride-2 data gradient: scattered rows
+                const int m = m0 + srow + i * RPI;
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+                const size_t orow = ((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b;
+                *reinterpret_cast<uint4*>(p.y + orow * p.Cout + n0 + sch * 8) = c;
+                continue;
+            }
+            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
+                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
+                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2)
+                    cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                          __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            }
+            if (p.addend2) {                                    // rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :]
+                const int m = m0 + srow + i * RPI;
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+                if (!((ho | wo) & 1)) {
+                    const size_t co = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8;
+                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend2 + co);
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2)
+                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+            }
+            if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
+                const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
+                const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
+                    if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                }
+                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            }
+            *reinterpret_cast<uint4*>(p.y + go) = c;
+        }
+    }
 }
 
 // PF = prefetch distance of the global loads in K-steps. The K loop is bound by load latency, not by MFMA or LDS
@@ -292,95 +395,162 @@ conv_igemm_kernel(ConvP p) {
 #undef CV_ST
 #undef CV_BL
 
-    // ---- epilogue: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free now) -> 16-B row stores
-    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row (padding: rows r, r+4 on disjoint banks)
-    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB)
-    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
-    float csum[NI], csq[NI];
+    cv_epilogue<BN>(p, acc, smem, t, m0, n0, mt);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the K loop: global -> LDS directly (buffer_load_dwordx4 ... lds), no staging registers and no
+// ds_write pass. The register-staged loop above spends more LDS-pipe cycles writing a K-tile (32 x ds_write_b128 = ~416
+// cycles per workgroup and K-step) than its MFMAs take to issue on a SIMD (16 x 32 = 512) once the 256 cycles of fragment
+// reads are added: the LDS pipe, not the matrix pipe, bounds it. A DMA piece is one wave-instruction = 1 KB = 8 LDS rows
+// of 128 B: lane l lands at row (l >> 3), physical 16-B chunk (l & 7) of its piece, so the XOR swizzle of the LDS image
+// ((row >> 1) & 7, same image as above: the fragment reads are unchanged) is applied to the lane's SOURCE address instead.
+// Out-of-image taps still go out of the buffer's range: the hardware writes zeros into LDS for those lanes.
+// Two LDS stages, tile kt+1 in flight while tile kt is multiplied, one barrier per K-step; 32 fewer VGPRs than the
+// register-staged kernel.
+// one DMA piece: 64 lanes x 16 B from (buffer, per-lane voffset + wave-uniform soffset) to the 1 KB of LDS at `lds`
+// (wave-uniform; it becomes M0). Out-of-range lanes write zeros.
+__device__ __forceinline__ void cv_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voffset, int soffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voffset, soffset, 0, 0);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(DIR_TPB)
+conv_igemm_dma_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
+    constexpr int B_BYTES = BN * CV_ROWB;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int BI = BN / 32;                           // B pieces per wave
+    constexpr int MI = (BN == 128) ? 2 : 1;
+    constexpr int NI = 2;
+    constexpr int WM = MI * 32;
+    int lin;
+    {
+        const int b = blockIdx.x, q = p.nblocks / 8, r = p.nblocks % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int mt = lin / p.ntn, nt = lin - mt * p.ntn;
+    const int m0 = mt * CV_BM, n0 = nt * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform by construction; tell the compiler (LDS base -> M0)
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    // ---- loader: piece i of this wave = rows wave*32 + 8 i + (lane >> 3) of the A tile (B: wave*8*BI + 8 i + (lane >> 3));
+    // the lane's LDS slot is physical chunk (lane & 7) of that row = logical chunk (lane & 7) ^ ((row >> 1) & 7), and
+    // (row >> 1) & 7 = (lane >> 4) | ((i & 1) << 2) for both tiles
+    const int lr = lane >> 3, lc = lane & 7;
+    int aoff[4];
+    uint32_t amask[4];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
-    unsigned char* cbase = Cs + (wm * WM + 4 * fhalf) * CS_STRIDE + (wn * 64 + frow) * 2;
-    if (p.stats) cv_stage_acc<MI, NI, CS_STRIDE, true>(acc, cbase, csum, csq);
-    else cv_stage_acc<MI, NI, CS_STRIDE, false>(acc, cbase, csum, csq);
-    if (p.stats) {
+    for (int i = 0; i < 4; ++i) {
+        const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+        const int m = m0 + wave * 32 + 8 * i + lr;
+        aoff[i] = 0; amask[i] = 0;
+        if (m < p.M) {
+            if (p.simple) { aoff[i] = (m * p.Cin + chunk * 8) * 2; amask[i] = 1u; continue; }
+            int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+            if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+            int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+            if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + chunk * 8) * 2;
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
+        }
+    }
+    const int K = p.KT * CV_BK;
+    int woff[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+        woff[i] = ((n0 + wave * 8 * BI + 8 * i + lr) * K + chunk * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0,
+                                                                           (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), (short)0,
+                                                                           (int)((unsigned)p.Cout * (unsigned)K * 2u), 0x00020000);
+    uint32_t af[MI][4], bf[NI][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * WM + mi * 32 + frow;
+            af[mi][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(af[mi][kk]));
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
-            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
-            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
+            const int row = wn * 64 + ni * 32 + frow;
+            bf[ni][kk] = A_BYTES + row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(bf[ni][kk]));
         }
     }
-    __syncthreads();
-    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
-        const int which = t / BN, col = t - which * BN;
-        float s = 0.0f;
-        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
-        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
-        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
+    int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0, ld_k = 0;
+
+#define CV_DMA(rs, ldsoff, vo, so) cv_dma16(rs, smem + (ldsoff), vo, so)
+#define CV_ISSUE_TILE(stage)                                                                                    \
+    {                                                                                                           \
+        const int koff = ((ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK) * 2;                                      \
+        const uint32_t bit = 1u << ld_tap;                                                                      \
+        const int abase = (stage) * STAGE + wave * 4096;                                                        \
+        CV_DMA(rs_x, abase + 0 * 1024, (amask[0] & bit) ? aoff[0] + koff : CV_OOB, 0);                          \
+        CV_DMA(rs_x, abase + 1 * 1024, (amask[1] & bit) ? aoff[1] + koff : CV_OOB, 0);                          \
+        CV_DMA(rs_x, abase + 2 * 1024, (amask[2] & bit) ? aoff[2] + koff : CV_OOB, 0);                          \
+        CV_DMA(rs_x, abase + 3 * 1024, (amask[3] & bit) ? aoff[3] + koff : CV_OOB, 0);                          \
+        const int wso = ld_k * CV_BK * 2;                                                                       \
+        const int bbase = (stage) * STAGE + A_BYTES + wave * (BI * 1024);                                       \
+        CV_DMA(rs_w, bbase + 0 * 1024, woff[0], wso);                                                           \
+        CV_DMA(rs_w, bbase + 1 * 1024, woff[1], wso);                                                           \
+        if (BI == 4) { CV_DMA(rs_w, bbase + 2 * 1024, woff[BI - 2], wso); CV_DMA(rs_w, bbase + 3 * 1024, woff[BI - 1], wso); } \
+        ++ld_k;                                                                                                 \
+        if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
     }
-    constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
-    constexpr int RPI = DIR_TPB / CPR;                          // rows per pass of the workgroup
-    const int srow = t / CPR, sch = t - srow * CPR;
-    const unsigned char* cs = Cs + srow * CS_STRIDE + sch * 16;
-    size_t go = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
-    const size_t gstep = (size_t)RPI * p.Cout;
-    const bool full = m0 + CV_BM <= p.M;
-#pragma unroll
-    for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
-        if (full || m0 + srow + i * RPI < p.M) {
-            uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
-            if (p.o2) {                                         // parity class of a stride-2 data gradient: scattered rows
-                const int m = m0 + srow + i * RPI;
-                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
-                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
-                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-                const size_t orow = ((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b;
-                *reinterpret_cast<uint4*>(p.y + orow * p.Cout + n0 + sch * 8) = c;
-                continue;
-            }
-            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
-                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
-                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2)
-                    cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
-                                          __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
-                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
-            if (p.addend2) {                                    // rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :]
-                const int m = m0 + srow + i * RPI;
-                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
-                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
-                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-                if (!((ho | wo) & 1)) {
-                    const size_t co = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8;
-                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend2 + co);
-                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                    for (int q2 = 0; q2 < 4; ++q2)
-                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
-                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
-                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-                }
-            }
-            if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
-                const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
-                const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
-                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
-                    if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
-                }
-                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
-            *reinterpret_cast<uint4*>(p.y + go) = c;
-        }
+#define CV_MFMA_STEP(stage)                                                                                     \
+    {                                                                                                           \
+        _Pragma("unroll")                                                                                       \
+        for (int kk = 0; kk < 4; ++kk) {                                                                        \
+            bf16x8 a[MI], b[NI];                                                                                \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + (stage) * STAGE + af[mi][kk]); \
+            _Pragma("unroll")                                                                                   \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + (stage) * STAGE + bf[ni][kk]); \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi)                                                                     \
+                _Pragma("unroll")                                                                               \
+                for (int ni = 0; ni < NI; ++ni)                                                                 \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+        }                                                                                                       \
     }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+    CV_ISSUE_TILE(0);
+    __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
+    for (int kt = 0; kt < p.KT; kt += 2) {                      // two K-steps per trip: stages 0 and 1 are literals
+        if (kt + 1 < p.KT) CV_ISSUE_TILE(1);
+        CV_MFMA_STEP(0);
+        __syncthreads();
+        if (kt + 1 >= p.KT) break;
+        if (kt + 2 < p.KT) CV_ISSUE_TILE(0);
+        CV_MFMA_STEP(1);
+        __syncthreads();
+    }
+#undef CV_MFMA_STEP
+#undef CV_ISSUE_TILE
+#undef CV_DMA
+    cv_epilogue<BN>(p, acc, smem, t, m0, n0, mt);
 }
 
 }  // namespace
@@ -398,7 +568,7 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
                        dir_stream_t stream);
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                          int cls_a, int cls_b, int reserved, dir_stream_t stream);
+                          int cls_a, int cls_b, int variant, dir_stream_t stream);
 
 extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
                                 int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
@@ -414,6 +584,14 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
                                   float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   dir_stream_t stream) {
     return conv_launch(x, w, addend, nullptr, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+}
+
+// A/B measurements and tests: the same convolution with the K-loop variant forced (0 = heuristic = dir_conv_fwd,
+// 1 = register-staged, 2 = LDS-DMA).
+extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
+                                    int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
+    DIR_RETURN_IF(variant < 0 || variant > 2, DIR_EINVAL);
+    return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
 
 extern "C" int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2,
@@ -447,7 +625,7 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
 // y [N, 2 H, 2 W, Cout]
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                          int cls_a, int cls_b, int /*reserved*/, dir_stream_t stream) {
+                          int cls_a, int cls_b, int variant, dir_stream_t stream) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
     DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || stats), DIR_EINVAL);
     DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
@@ -479,18 +657,26 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     p.ntn = wide ? Cout / 128 : Cout / 64;
     p.nblocks = mtiles * p.ntn;
     hipStream_t s = dir_s(stream);
-    // LDS stages: 2 (64 KB, 2 workgroups per CU) for long K loops, 1 (43 KB, 3 per CU) when the loop is short and the
-    // layer is bound by memory latency rather than by MFMA issue. DIR_CONV_NBUF=1|2 overrides (experiments).
-    static const int force_nbuf = []() { const char* e = getenv("DIR_CONV_NBUF"); return e ? atoi(e) : 0; }();
-    static const int nbuf_kt = []() { const char* e = getenv("DIR_CONV_NBUF_KT"); return e ? atoi(e) : 18; }();
-    p.nbuf = force_nbuf ? force_nbuf : (p.KT <= nbuf_kt ? 1 : 2);
-    // Prefetch distance: 2 K-tiles in flight per workgroup once the loop is long enough to use them (DIR_CONV_PF=1|2
-    // overrides, DIR_CONV_PF_KT = shortest loop that gets PF = 2).
-    static const int force_pf = []() { const char* e = getenv("DIR_CONV_PF"); return e ? atoi(e) : 0; }();
-    static const int pf_kt = []() { const char* e = getenv("DIR_CONV_PF_KT"); return e ? atoi(e) : 36; }();
-    const int pf = force_pf ? force_pf : (p.KT >= pf_kt ? 2 : 1);
+    // K-loop variant. 2 = LDS-DMA (two 32/24 KB stages, no staging registers): loops of >= CV_DMA_MIN_KT steps, where the LDS
+    // pipe bounds the register-staged loop. 1 = register-staged: LDS stages 2 (64 KB, 2 workgroups per CU) for long K loops,
+    // 1 (43 KB, 3 per CU, one extra barrier) when the loop is short and the layer is bound by memory latency; prefetch
+    // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int bn = wide ? 128 : 64;
     const int stage = CV_BM * (bn * 2 + 64) + 2048;                 // epilogue staging + column partials
+    const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
+    if (dma) {
+        const int loop2 = 2 * (CV_BM * CV_ROWB + bn * CV_ROWB);
+        const int lds2 = loop2 > stage ? loop2 : stage;
+        static bool once_dma = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
+                                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
+        (void)once_dma;
+        if (wide) hipLaunchKernelGGL((conv_igemm_dma_kernel<128>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
+        else hipLaunchKernelGGL((conv_igemm_dma_kernel<64>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
+        DIR_LAUNCH_CHECK();
+        return DIR_OK;
+    }
+    p.nbuf = p.KT <= 18 ? 1 : 2;
+    const int pf = p.KT >= 36 ? 2 : 1;
     if (pf == 2) p.nbuf = 2;                                        // the two-tile prefetch is written for two LDS stages
     const int loop2 = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
     const int lds2 = loop2 > stage ? loop2 : stage;

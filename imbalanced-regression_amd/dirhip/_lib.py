@@ -67,6 +67,7 @@ SIGNATURES = {
     "dir_conv_dgrad_join": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "dir_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_void_p]),
+    "dir_conv_fwd_variant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dir_conv_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_void_p, c_size_t, c_void_p]),

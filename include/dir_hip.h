@@ -296,6 +296,11 @@ size_t dir_stem_conv_wgrad_workspace(int N, int H);
 int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, void* workspace,
                         size_t workspace_bytes, dir_stream_t stream);
 
+/* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd,
+ * 1 = register-staged loop (global -> VGPR -> ds_write), 2 = LDS-DMA loop (buffer_load ... lds, two stages). */
+int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
+                         int R, int S, int stride, int pad, int variant, dir_stream_t stream);
+
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
  * (float32 output, layout [Cout][R][S][Cin] = a channels_last [Cout, Cin, R, S] tensor).  MFMA GEMM with the
  * batch*pixel axis as K, operands transposed in registers on their way into LDS, deterministic split-K through
