@@ -94,6 +94,9 @@ SIGNATURES = {
     "dir_maxpool3x3s2_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_avgpool_f32_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dir_avgpool_f32_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dir_tail_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9),
+    "dir_tail_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "dir_tail_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_probe_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_probe_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_probe_mfma_bf16": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -26,6 +26,7 @@ from .conv import conv_bn_input, projection_pair, projection_pair_ok, stem_conv,
 from .conv_f32 import conv_f32, conv_ok
 from .fds import FDS
 from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
+from .tail import fusable as tail_fusable, tail_forward
 
 print = logging.info
 
@@ -164,8 +165,8 @@ class ResNet(nn.Module):
         stages += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*stages)
 
-    def features(self, x):
-        """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
+    def feature_map(self, x):
+        """The conv stack up to the last stage's output [B, 2048, 7, 7] (resnet.py:128-135)."""
         partial = None
         amp_bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
         if amp_bf16 and stem_conv_ok(x, self.conv1):
@@ -175,8 +176,11 @@ class ResNet(nn.Module):
             if amp_bf16:
                 x = x.to(torch.bfloat16)
         x = bn_relu_maxpool(x, self.bn1, self.maxpool, partial=partial)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        return global_avgpool_flat(x, self.avgpool)
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+    def features(self, x):
+        """conv stack + global 7x7 average pool -> [B, 2048] (resnet.py:128-138)."""
+        return global_avgpool_flat(self.feature_map(x), self.avgpool)
 
     def _batch_counters(self):
         bc = getattr(self, "_dir_counters", None)
@@ -188,20 +192,26 @@ class ResNet(nn.Module):
 
     def forward(self, x, targets=None, epoch=None):
         counters = self._batch_counters() if self.training else None
-        encoding = self.features(x)
+        fmap = self.feature_map(x)
         if counters is not None:
             counters.flush()
-        # the FDS / linear / loss tail is fp32 whatever precision the conv stack ran in
-        with torch.autocast(device_type=encoding.device.type, enabled=False):
-            if encoding.dtype != torch.float32:
-                encoding = encoding.float()
-            encoding_s = encoding
-            if self.training and self.fds:
-                if epoch >= self.start_smooth:
+        smooth = bool(self.training and self.fds and epoch >= self.start_smooth)
+        # the pool / FDS / linear / loss tail is fp32 whatever precision the conv stack ran in
+        with torch.autocast(device_type=fmap.device.type, enabled=False):
+            if not self.use_dropout and tail_fusable(fmap, self.avgpool, self.linear):
+                # pool -> FDS.smooth -> linear as ONE kernel; `encoding` is the calibrated tensor (in the reference smooth()
+                # is in place and the same object is returned, A.2)
+                x, encoding = tail_forward(fmap, self.linear, self.FDS if smooth else None, targets)
+            else:
+                encoding = global_avgpool_flat(fmap, self.avgpool)
+                if encoding.dtype != torch.float32:
+                    encoding = encoding.float()
+                encoding_s = encoding
+                if smooth:
                     encoding_s = self.FDS.smooth(encoding_s, targets, epoch)     # in place (A.2)
-            if self.use_dropout:
-                encoding_s = self.dropout(encoding_s)
-            x = self.linear(encoding_s)
+                if self.use_dropout:
+                    encoding_s = self.dropout(encoding_s)
+                x = self.linear(encoding_s)
 
         if self.training and self.fds:
             return x, encoding

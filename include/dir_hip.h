@@ -403,6 +403,29 @@ int dir_avgpool_f32_fwd(const float* x, float* y, int N, int HW, int C, dir_stre
 int dir_avgpool_f32_bwd(const float* dy, float* dx, int N, int HW, int C, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused network tail: AvgPool2d(7) + view -> FDS.smooth -> Linear(2048, 1)
+ * (imdb-wiki-dir/resnet.py:136-148, fds.py:115-144) in ONE launch, and its backward.
+ *   x [B, HW, C] (dtype DIR_BF16 or DIR_F32, NHWC map of the last stage), weight [C] f32, bias [1] f32.
+ *   calibration: m1 / scale / m2 [nb, C] f32 (scale from dir_fds_prepare_scale) — all three NULL = no calibration
+ *   (epoch < start_smooth, eval mode, FDS off).  The sample's bucket comes from `labels` [B] f32 (boundary presence
+ *   flags over THIS batch, SURVEY A.3, like dir_fds_smooth_fwd; use for B <= 2048) or from `bins_in` [B] (dir_fds_bin_index).
+ *   out: encoding [B, C] f32 = the CALIBRATED pooled features (the tensor resnet.py returns as `encoding`, A.2),
+ *        pred [B] f32 = encoding . weight + bias,  bins_out [B] int32 (required when calibrating; saved for the backward).
+ * dir_tail_bwd: dx [B, HW, C] (dtype) = ((dpred[b] * weight[c] (+ dencoding[b, c])) * s[bin_b, c]) / HW   (dx NULL = skip),
+ *        dweight [C] = sum_b dpred[b] * encoding[b, c], dbias [1] = sum_b dpred[b]  (dweight NULL = skip both); fixed
+ *        summation order.  workspace >= dir_tail_bwd_workspace(B, C) bytes.  bins NULL = no calibration in the forward.
+ * Arithmetic is float32 and written like the unfused chain (dir_avgpool_* -> dir_fds_smooth_fwd / dir_fds_calibrate_bwd),
+ * so encoding and dx are bit-identical to it; pred / dweight differ from a library gemv by summation order only. */
+int dir_tail_fwd(const void* x, int dtype, const float* labels, const int32_t* bins_in, int B, int HW, int C,
+                 int bucket_start, int bucket_num, const float* m1, const float* scale, const float* m2,
+                 const float* weight, const float* bias, float* encoding, float* pred, int32_t* bins_out,
+                 dir_stream_t stream);
+size_t dir_tail_bwd_workspace(int B, int C);
+int dir_tail_bwd(const float* dpred, const float* dencoding, const int32_t* bins, const float* scale, const float* weight,
+                 const float* encoding, int B, int HW, int C, int dtype, void* dx, float* dweight, float* dbias,
+                 void* workspace, size_t workspace_bytes, dir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Box calibration probes (measured STREAM-style HBM number and measured MFMA peak of THIS box, reported
  * next to the nominal 8 TB/s / 2.5 PFLOP/s).  Not part of the reference's path; bench.py times them with HIP events.
  *   dir_probe_stream_copy: dst[i] = src[i], 16 B per lane, 2048 workgroups grid-stride  (moves 2 * bytes)

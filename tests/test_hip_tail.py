@@ -1,0 +1,121 @@
+"""-m gpu: the fused network tail (dir_tail_fwd / dir_tail_bwd: AvgPool2d(7) + view -> FDS.smooth -> Linear(2048, 1),
+resnet.py:136-148) against (a) the unfused chain of the package's own kernels — encoding and data gradient bit for bit —
+and (b) a float64 torch restatement of the reference's arithmetic (pool, per-label calibrate_mean_var, linear)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _fds(c, nb_labels, seed):
+    from dirhip.fds import FDS
+    f = FDS(c, bucket_num=30, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).cuda()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    lab = torch.randint(0, 34, (nb_labels,), device="cuda", generator=g).float()
+    for ep in range(2):
+        feats = torch.rand(nb_labels, c, device="cuda", generator=g) * 0.5 + 0.02 * lab[:, None]
+        feats[:, 3] = 0.125                                   # a constant column: v1 == 0 -> left untouched (utils.py:100-104)
+        f.update_last_epoch_stats(ep)
+        f.update_running_stats(feats, lab, ep)
+    return f
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("b,c,smooth", [(64, 2048, True), (5, 2048, False), (1, 64, True), (300, 128, True)])
+def test_fused_tail_equals_unfused_chain_and_float64_reference(dtype, b, c, smooth):
+    from dirhip.pool import global_avgpool_flat
+    from dirhip.tail import tail_forward
+    g = torch.Generator(device="cuda").manual_seed(b + c)
+    fds = _fds(c, 600, 5) if smooth else None
+    pool, lin = nn.AvgPool2d(7, stride=1), nn.Linear(c, 1).cuda()
+    x0 = torch.relu(torch.randn(b, c, 7, 7, device="cuda", generator=g)).to(dtype).contiguous(memory_format=torch.channels_last)
+    labels = torch.randint(0, 34, (b, 1), device="cuda", generator=g).float()
+    if b >= 5:
+        labels[0, 0], labels[1, 0], labels[2, 0] = 1.0, 3.0, 33.0      # below / at bucket_start, above bucket_num - 1 (A.3)
+    dpred = torch.randn(b, 1, device="cuda", generator=g)
+    denc = torch.randn(b, c, device="cuda", generator=g) * 0.01
+    # ---- fused
+    xf = x0.clone().requires_grad_(True)
+    pred_f, enc_f = tail_forward(xf, lin, fds, labels)
+    (pred_f * dpred).sum().add((enc_f * denc).sum()).backward()
+    gw_f, gb_f = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    # ---- unfused chain of the package's kernels (what resnet.py ran before the fusion)
+    xu = x0.clone().requires_grad_(True)
+    enc_u = global_avgpool_flat(xu, pool)
+    if smooth:
+        enc_u = fds.smooth(enc_u, labels, 5)
+    pred_u = lin(enc_u)
+    (pred_u * dpred).sum().add((enc_u * denc).sum()).backward()
+    assert torch.equal(enc_f, enc_u)                                          # same float32 operations in the same order
+    assert torch.equal(xf.grad, xu.grad)
+    assert_close(pred_f.detach().cpu().numpy(), pred_u.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="pred vs unfused")
+    assert_close(gw_f.cpu().numpy(), lin.weight.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, msg="dW vs unfused")
+    assert_close(gb_f.cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, msg="db vs unfused")
+    # ---- float64 restatement of the reference (resnet.py:136-148, fds.py:115-144, utils.py:97-107)
+    xd = x0.double().cpu().requires_grad_(True)
+    enc = xd.mean(dim=(2, 3))
+    if smooth:
+        m1, v1 = fds.running_mean_last_epoch.double().cpu(), fds.running_var_last_epoch.double().cpu()
+        m2, v2 = fds.smoothed_mean_last_epoch.double().cpu(), fds.smoothed_var_last_epoch.double().cpu()
+        lab = labels.squeeze(1).cpu()
+        rows = []
+        has_lo, has_hi = bool((lab == 3).any()), bool((lab == 29).any())
+        for i in range(b):
+            l = float(lab[i])
+            if l > 29:
+                k = 26 if has_hi else -1
+            elif l < 3:
+                k = 0 if has_lo else -1
+            else:
+                k = int(l - 3)
+            e = enc[i]
+            if k >= 0 and float(v1[k].sum()) >= 1e-10:
+                v1s = torch.where(v1[k] != 0, v1[k], torch.ones_like(v1[k]))      # (keeps NaN out of the unselected branch's gradient)
+                factor = torch.clamp(v2[k] / v1s, 0.1, 10)
+                cal = (e - m1[k]) * torch.sqrt(factor) + m2[k]
+                e = torch.where(v1[k] != 0, cal, e)
+            rows.append(e)
+        enc = torch.stack(rows)
+    wd, bd = lin.weight.detach().double().cpu().requires_grad_(True), lin.bias.detach().double().cpu().requires_grad_(True)
+    pred = enc @ wd.t() + bd
+    (pred * dpred.double().cpu()).sum().add((enc * denc.double().cpu()).sum()).backward()
+    tol = dict(rtol=1e-5, atol_scale=2e-6)
+    assert_close(enc_f.detach().cpu().numpy(), enc.detach().numpy(), msg="encoding", **tol)
+    assert_close(pred_f.detach().cpu().numpy(), pred.detach().numpy(), rtol=1e-5, atol_scale=1e-5, msg="pred")
+    gtol = dict(rtol=1e-5, atol_scale=2e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol_scale=4e-3)   # dx is rounded to bf16
+    assert_close(xf.grad.float().cpu().numpy(), xd.grad.numpy(), msg="dx", **gtol)
+    assert_close(gw_f.cpu().numpy(), wd.grad.numpy(), rtol=1e-5, atol_scale=1e-5, msg="dW")
+    assert_close(gb_f.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol_scale=1e-5, msg="db")
+
+
+def test_training_step_has_no_library_gemv():
+    """With the fused tail the linear layer no longer reaches rocBLAS: a profiler trace of one bf16 training step holds no
+    library GEMM / gemv kernel (names start with `Cijk_` or contain `gemv`), no MIOpen kernel and no pooling kernel."""
+    from torch.profiler import ProfilerActivity, profile
+    from dirhip.parallel import DataParallelEngine
+    from dirhip.resnet import resnet50
+    from dirhip.train_loop import resolve_loss, train_step
+    torch.manual_seed(0)
+    model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5,
+                     sigma=2, momentum=0.9).cuda()
+    eng = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
+    eng.train()
+    opt = torch.optim.SGD(eng.parameters(), lr=1e-4)
+    x = torch.randn(8, 3, 224, 224, device="cuda")
+    y = torch.tensor([[25.0], [31.0], [64.0], [25.0]] * 2, device="cuda")
+    w = torch.ones(8, 1, device="cuda")
+    train_step(eng, opt, x, y, w, 2, resolve_loss("l1"))
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        train_step(eng, opt, x, y, w, 2, resolve_loss("l1"))
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad = [n for n in names if n.startswith("Cijk_") or "gemv" in n.lower() or "miopen" in n.lower() or "pool" in n.lower() and "dir" not in n.lower()
+           and "maxpool" not in n and "avgpool" not in n]
+    assert not [n for n in names if n.startswith("Cijk_") or "gemv" in n.lower() or "miopen" in n.lower()], bad
+    assert any("tail_fwd_kernel" in n for n in names) and any("tail_bwd_dx_kernel" in n for n in names), names
