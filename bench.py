@@ -5,23 +5,33 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d config 2, per GPU): IMDB-WIKI-DIR shapes — ResNet-50,
-bf16 conv stack, B=256 synthetic 224x224 batches, LDS weights (sqrt_inv, gaussian 5/2) from a synthetic
-191 509-label long-tailed set, FDS (bucket_num=100, bucket_start=0, ks=5, sigma=2, momentum 0.9) with tables
-populated by two update rounds and the run at epoch >= 2 so calibration is non-trivial (A.4), loss l1, Adam 1e-3.
+Workload (BASELINE.json configs[1], SURVEY.md §8d config 2, per GPU): IMDB-WIKI-DIR shapes — ResNet-50, bf16 conv stack,
+B=256 synthetic 224x224 batches, LDS weights (sqrt_inv, gaussian 5/2) from a synthetic 191 509-label long-tailed set, FDS
+(bucket_num=100, bucket_start=0, ks=5, sigma=2, momentum 0.9) with tables populated by two update rounds and the run at
+epoch >= 2 so calibration is non-trivial (A.4), loss l1, Adam 1e-3.
 
-A "step" is one optimisation step (train.py:246-262). Nothing of the hot path is skipped: every
---epoch-len steps the timed region also runs the reference's epoch tail (train.py:269-281) over the same
-number of batches — the no-grad train-mode feature pass, FDS.update_last_epoch_stats and
-FDS.update_running_stats (with the cross-rank statistic all-reduce when N > 1). `value` counts trained
-images only (K * B * N / time), so it is the throughput of the whole loop, tail included;
-`train_only_images_per_sec` is the same clock without the tail, for comparison with plain ResNet-50 numbers.
+A "step" is one optimisation step (train.py:246-262). Nothing of the hot path is skipped: every --epoch-len steps the timed
+region also runs the reference's epoch tail (train.py:269-281) over the same number of batches — the no-grad train-mode
+feature pass, FDS.update_last_epoch_stats and FDS.update_running_stats (with the cross-rank statistic all-reduce when
+N > 1). `value` counts trained images only (K * B * N / time), so it is the throughput of the whole loop, tail included;
+`train_only_images_per_sec` is the same clock without the tail.
 
-Rank 0 prints ONE JSON line. Extra legs on rank 0 at N=1 after the timed region: hand-written-kernel
-micro-rooflines (HIP events on the launch stream) and the CPU baseline (oracle/torch_oracle.py = a torch-CPU
-port of the reference loop, timed on the host cores on a bounded sample).
+Rank 0 prints ONE JSON line. After the timed region, rank 0 at N=1 also measures (none of it inside `value`):
+  * `roofline` — the dominant kernel family, the MFMA implicit-GEMM convolution (conv_igemm_*: 52 forward + 49 stride-1 /
+    compact data-gradient + 12 parity-class launches per step), IN SITU: per-kernel device times of whole training steps
+    from the profiler's kernel trace (the same numbers `rocprofv3 --kernel-trace` of this command reports;
+    profiles/rNN_train_step_breakdown.txt), against the algorithmic FLOPs of those launches;
+  * `kernel_rooflines` — the other hand-written kernels in situ (weight gradient, BatchNorm family, tail) and the FDS
+    kernels at their full-epoch sizes, each with algorithmic bytes / FLOPs from SURVEY.md §8d;
+  * `conv_layers` — every conv shape alone (forward, data gradient, weight gradient) with inputs rotated over > 256 MB
+    of distinct buffers (nothing Infinity-Cache resident) next to its own roofline max(FLOP / peak, bytes / HBM);
+  * `peaks` — STREAM-style copy / read bandwidth and bf16 / f32 MFMA issue rate measured on THIS box (dir_probe_*);
+    every fraction is quoted against the nominal peak (MI355X_MICROARCH.md) and against the measured one;
+  * `cpu_baseline` — the reference loop's torch-CPU port (oracle/torch_oracle.py, pinned to the live reference) on the
+    host cores: the whole loop at B=8, plus the SURVEY §8d micro-baselines (FDS.smooth, update_running_stats, the losses).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -42,6 +52,14 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec, MI355X_MICROARCH.md (achievable ~630
 N_TRAIN = 191509              # IMDB-WIKI-DIR train-set size (paper; the csv is not vendored)
 _T0 = time.time()
 
+# ResNet-50 convolutions on the MFMA implicit-GEMM kernels (every layer but the 7x7 stem):
+# (Cin, Cout, k, stride, Hin, count) — SURVEY.md Appendix B
+RESNET50_CONVS = [(64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2), (256, 128, 1, 1, 56, 1),
+                  (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1), (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3),
+                  (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1), (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5),
+                  (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
+                  (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2)]
+
 
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
@@ -51,6 +69,15 @@ def log(*a):
 def long_tail_labels(rng, n):
     """Fixed long-tailed pmf over integer ages 0..120: round(clip(|N(0,18)| + 20, 0, 120))."""
     return np.clip(np.round(np.abs(rng.normal(0, 18, n)) + 20), 0, 120).astype(np.float32)
+
+
+def conv_flops_per_image():
+    """Forward FLOPs per image of the 52 implicit-GEMM layers (2 * Ho*Wo * Cout * Cin * k*k each)."""
+    tot = 0.0
+    for cin, cout, k, st, h, cnt in RESNET50_CONVS:
+        ho = (h + 2 * (k // 2) - k) // st + 1
+        tot += cnt * 2.0 * ho * ho * cout * cin * k * k
+    return tot
 
 
 def build(args, device, rank):
@@ -123,35 +150,144 @@ def timed(fn, device, world):
 
 
 def event_time_ms(fn, iters, warm=3):
-    """Average duration of fn() over `iters` launches with HIP events on torch's current stream
+    """Average duration of fn(i) over `iters` launches with HIP events on torch's current stream
     (= the stream the C-ABI launches on)."""
-    for _ in range(warm):
-        fn()
+    for i in range(warm):
+        fn(i)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        fn(i)
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 
 
-def kernel_rooflines(device):
-    """Algorithmic bytes / measured duration for the hand-written FDS kernels."""
+def measured_peaks(device):
+    """STREAM-style HBM bandwidth and MFMA issue peaks of this box (csrc/dir_probe.hip), HIP events on the launch stream."""
+    from dirhip import _lib as L
+    lib = L.lib()
+    st = L.stream_ptr(device)
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    red = torch.empty(8192, dtype=torch.float32, device=device)
+    out = {"nominal": {"hbm_GBs": PEAK_HBM_GBS, "bf16_mfma_TFs": PEAK_BF16_TFLOPS, "f32_mfma_TFs": 157.3}}
+    ms = event_time_ms(lambda i: L.check(lib.dir_probe_stream_copy(L.ptr(src), L.ptr(dst), nbytes, st), "copy"), 10)
+    out["stream_copy_GBs"] = 2 * nbytes / ms / 1e6
+    ms = event_time_ms(lambda i: L.check(lib.dir_probe_stream_read(L.ptr(src), L.ptr(red), nbytes, st), "read"), 10)
+    out["stream_read_GBs"] = nbytes / ms / 1e6
+    del src, dst
+    wgs = 256 * 8
+    buf = torch.empty(wgs * 256, dtype=torch.float32, device=device)
+    fl = ctypes.c_double(0.0)
+    for name, fn, iters in (("bf16_mfma_TFs", lib.dir_probe_mfma_bf16, 2000), ("f32_mfma_TFs", lib.dir_probe_mfma_f32, 500)):
+        ms = event_time_ms(lambda i: L.check(fn(wgs, iters, L.ptr(buf), ctypes.byref(fl), st), name), 5)
+        out[name] = fl.value / ms / 1e9
+    return out
+
+
+FAMILIES = (("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
+            ("bn_", "batchnorm"), ("tail_", "tail"), ("fds_", "fds"), ("loss_", "loss"), ("scale_by_scalar", "loss"),
+            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"))
+
+
+def in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch, steps=4):
+    """Device time of every kernel of `steps` whole training steps (profiler kernel trace = roctracer, the data rocprofv3
+    --kernel-trace records), per kernel family and per step."""
+    from torch.profiler import ProfilerActivity, profile
+    from dirhip.train_loop import train_step
+    for s in range(2):
+        train_step(engine, optimizer, *batches[s % len(batches)], epoch, loss_fn)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for s in range(steps):
+            train_step(engine, optimizer, *batches[s % len(batches)], epoch, loss_fn)
+        torch.cuda.synchronize()
+    fam = {}
+    for e in prof.key_averages():
+        tot = getattr(e, "device_time_total", None)
+        if tot is None:
+            tot = getattr(e, "cuda_time_total", 0.0)
+        if not tot:
+            continue
+        name = e.key
+        tag = "other"
+        for needle, t in FAMILIES:
+            if needle in name:
+                tag = t
+                break
+        f = fam.setdefault(tag, {"us_per_step": 0.0, "launches_per_step": 0.0})
+        f["us_per_step"] += tot / steps
+        f["launches_per_step"] += e.count / steps
+    return fam
+
+
+def conv_layer_probe(device, batch):
+    """Every conv shape alone: forward (incl. BatchNorm statistics), data gradient (stride-1: the same kernel on dY;
+    3x3 stride-2: four parity-class launches; 1x1 stride-2: the compact 1x1 GEMM on dY) and weight gradient, inputs rotated
+    over > 256 MB of distinct buffers. Returns rows [cin, cout, k, stride, H, count, kind, us, roofline_us, launches]."""
+    from dirhip import _lib as L
+    from dirhip.conv import conv2d_igemm, conv2d_wgrad
+    rows = []
+    lib = L.lib()
+
+    def bufs(shape, nbytes_pair):
+        n = max(2, min(8, int(400e6 // nbytes_pair) + 1))
+        return [torch.randn(shape, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(n)]
+    for cin, cout, k, st, h, cnt in RESNET50_CONVS:
+        pad = k // 2
+        ho = (h + 2 * pad - k) // st + 1
+        flop = 2.0 * batch * ho * ho * cout * cin * k * k
+        nbytes = (batch * h * h * cin + batch * ho * ho * cout) * 2
+        roof_us = max(flop / (PEAK_BF16_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)) * 1e6
+        xs = bufs((batch, cin, h, h), nbytes)
+        dys = bufs((batch, cout, ho, ho), nbytes)
+        w = (torch.randn(cout, cin, k, k, device=device) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        nb = len(xs)
+        ms = event_time_ms(lambda i: conv2d_igemm(xs[i % nb], w, st, pad, want_stats=True), 8, warm=2)
+        rows.append([cin, cout, k, st, h, cnt, "fwd", ms * 1e3, roof_us, 1])
+        if st == 1:
+            wr = (torch.randn(cin, cout, k, k, device=device) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            ms = event_time_ms(lambda i: conv2d_igemm(dys[i % nb], wr, 1, pad), 8, warm=2)
+            rows.append([cin, cout, k, st, h, cnt, "dgrad", ms * 1e3, roof_us, 1])
+        elif k == 3:
+            wf = torch.randn(cout, cin, 3, 3, device=device).contiguous(memory_format=torch.channels_last)
+            w16 = torch.empty((cout, cin, 3, 3), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+            wcls = torch.empty(cin * 9 * cout, dtype=torch.bfloat16, device=device)
+            L.check(lib.dir_conv_prep_weights_ex(L.ptr(wf), cout, 3, 3, cin, L.ptr(w16), L.ptr(wcls), 1, L.stream_ptr(device)), "prep")
+            dxs = [torch.empty((batch, cin, h, h), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+            ms = event_time_ms(lambda i: L.check(lib.dir_conv_dgrad_s2(L.ptr(dys[i % nb]), L.ptr(wcls), L.ptr(dxs[i % 2]), batch, ho, ho, cout, cin,
+                                                                       L.stream_ptr(device)), "dgrad_s2"), 8, warm=2)
+            rows.append([cin, cout, k, st, h, cnt, "dgrad(4 parity classes)", ms * 1e3, roof_us, 4])
+        else:
+            wr = (torch.randn(cin, cout, 1, 1, device=device) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            ms = event_time_ms(lambda i: conv2d_igemm(dys[i % nb], wr, 1, 0), 8, warm=2)
+            cb = (batch * ho * ho * (cin + cout)) * 2
+            rows.append([cin, cout, k, st, h, cnt, "dgrad(compact)", ms * 1e3, max(flop / (PEAK_BF16_TFLOPS * 1e12), cb / (PEAK_HBM_GBS * 1e9)) * 1e6, 1])
+        ms = event_time_ms(lambda i: conv2d_wgrad(dys[i % nb], xs[i % nb], k, st, pad), 8, warm=2)
+        rows.append([cin, cout, k, st, h, cnt, "wgrad", ms * 1e3, roof_us, 2])
+        del xs, dys, w
+    return rows
+
+
+def fds_kernel_rooflines(device):
+    """Algorithmic bytes / measured duration for the hand-written FDS kernels at their full sizes."""
     from dirhip import ops
     out = []
     g = torch.Generator(device=device).manual_seed(3)
+
+    def row(kernel, bound, shape, ms, alg):
+        return {"kernel": kernel, "bound": bound, "shape": shape, "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS}
     # --- dir_fds_scatter_stats over the whole epoch's features: N*C*4 + N*4 bytes read
     n, c, nb = N_TRAIN, 2048, 100
     lab = torch.as_tensor(long_tail_labels(np.random.default_rng(3), n), device=device)
     feats = torch.randn(n, c, device=device, generator=g).abs_()
     bins, _ = ops.bin_index(lab, 0, 100)
-    ms = event_time_ms(lambda: ops.scatter_stats(feats, bins, nb), 10)
-    alg = n * c * 4 + n * 4
-    out.append({"kernel": "dir_fds_scatter_stats (5 launches: group x3, piece sums, combine)", "bound": "hbm",
-                "shape": f"N={n} C={c} Nb={nb} f32", "ms": ms, "algorithmic_bytes": alg,
-                "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+    ms = event_time_ms(lambda i: ops.scatter_stats(feats, bins, nb), 10)
+    out.append(row("dir_fds_scatter_stats (grouping + piece sums + combine)", "hbm", f"N={n} C={c} Nb={nb} f32", ms, n * c * 4 + n * 4))
     del feats
     # --- calibrate forward: 2*B*C*4 + T*U*C*4 + B*4, T = 3 tables (m1, scale, m2; scale precomputed per epoch)
     for b in (256, 65536):
@@ -161,120 +297,36 @@ def kernel_rooflines(device):
         sc = torch.rand(nb, c, device=device, generator=g) + 0.5
         m2 = torch.randn(nb, c, device=device, generator=g)
         u = int(torch.unique(labb.clamp(max=99)).numel())
-        ms = event_time_ms(lambda: ops.smooth_fwd_(x, labb, 0, 100, m1, sc, m2), 50 if b == 256 else 10)
-        alg = 2 * b * c * 4 + 3 * u * c * 4 + b * 4
-        out.append({"kernel": "dir_fds_smooth_fwd (K1+K5 fused)" if b <= 2048 else "dir_fds_smooth_fwd (K1, K5)",
-                    "bound": "hbm" if b > 2048 else "launch", "shape": f"B={b} C={c} U={u} T=3 f32", "ms": ms,
-                    "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+        ms = event_time_ms(lambda i: ops.smooth_fwd_(x, labb, 0, 100, m1, sc, m2), 50 if b == 256 else 10)
+        out.append(row("dir_fds_smooth_fwd (K1+K5 fused)" if b <= 2048 else "dir_fds_smooth_fwd (K1, K5)", "hbm" if b > 2048 else "launch",
+                       f"B={b} C={c} U={u} T=3 f32", ms, 2 * b * c * 4 + 3 * u * c * 4 + b * 4))
         bins_b, _ = ops.bin_index(labb, 0, 100)
         dy = torch.randn(b, c, device=device, generator=g)
-        ms = event_time_ms(lambda: ops.calibrate_bwd(dy, bins_b, sc), 50 if b == 256 else 10)
-        alg = 2 * b * c * 4 + u * c * 4 + b * 4
-        out.append({"kernel": "dir_fds_calibrate_bwd", "bound": "hbm" if b > 2048 else "launch",
-                    "shape": f"B={b} C={c} U={u} f32", "ms": ms, "algorithmic_bytes": alg,
-                    "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+        ms = event_time_ms(lambda i: ops.calibrate_bwd(dy, bins_b, sc), 50 if b == 256 else 10)
+        out.append(row("dir_fds_calibrate_bwd", "hbm" if b > 2048 else "launch", f"B={b} C={c} U={u} f32", ms, 2 * b * c * 4 + u * c * 4 + b * 4))
         del x, dy
-    # --- "next" rows: NYUD2 dense map [32,128,114,152] (per-pixel buckets, narrow-row kernels) and STS-B [128,12000]
+    # --- "next" rows: NYUD2 dense map [32,128,114,152] (per-pixel buckets, narrow-row kernels)
     b, c, h, w = 32, 128, 114, 152
     depth = torch.rand(b * h * w, device=device, generator=g) * 9.3 + 0.7
     rows = torch.rand(b * h * w, c, device=device, generator=g)
     bins = ops.bin_scaled(depth, 10.0, 7, 100)
     t1, sc, t2 = (torch.rand(93, c, device=device, generator=g) + 0.5 for _ in range(3))
-    ms = event_time_ms(lambda: ops.calibrate_fwd_(rows, bins, t1, sc, t2), 10)
-    alg = 2 * rows.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4
-    out.append({"kernel": "dir_fds_calibrate_fwd (narrow rows, NYUD2 dense map)", "bound": "hbm", "shape": f"[{b},{c},{h},{w}] f32, 93 buckets",
-                "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
-    ms = event_time_ms(lambda: ops.scatter_stats(rows, bins, 93), 5)
-    alg = rows.numel() * 4 + rows.shape[0] * 4
-    out.append({"kernel": "dir_fds_scatter_stats (narrow rows, NYUD2 dense map)", "bound": "hbm", "shape": f"N={rows.shape[0]} C={c} Nb=93 f32",
-                "ms": ms, "algorithmic_bytes": alg, "achieved": alg / ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / ms / 1e6 / PEAK_HBM_GBS})
+    ms = event_time_ms(lambda i: ops.calibrate_fwd_(rows, bins, t1, sc, t2), 10)
+    out.append(row("dir_fds_calibrate_fwd (narrow rows, NYUD2 dense map)", "hbm", f"[{b},{c},{h},{w}] f32, 93 buckets", ms,
+                   2 * rows.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4))
+    ms = event_time_ms(lambda i: ops.scatter_stats(rows, bins, 93), 5)
+    out.append(row("dir_fds_scatter_stats (narrow rows, NYUD2 dense map)", "hbm", f"N={rows.shape[0]} C={c} Nb=93 f32", ms,
+                   rows.numel() * 4 + rows.shape[0] * 4))
     del rows
     return out
 
 
-# ResNet-50 convolutions that run on the hand-written MFMA kernel (every layer but the 7x7 stem):
-# (Cin, Cout, k, stride, Hin, count) — SURVEY.md Appendix B
-RESNET50_CONVS = [(64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2), (256, 128, 1, 1, 56, 1),
-                  (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1), (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3),
-                  (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1), (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5),
-                  (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
-                  (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2)]
-
-
-def conv_roofline(device, batch):
-    """Dominant kernel of the step = conv_igemm_kernel (forward + stride-1 data-gradient launches, ~1/3 of the GPU
-    time). Algorithmic FLOPs per launch = 2*M*Cout*Cin*R*S (implicit GEMM, SURVEY.md §8d: 8.174 GFLOP/image forward);
-    duration = HIP events on the launch stream, 5 launches per layer shape, every layer shape of the network in its
-    forward and (stride-1 layers) data-gradient configuration."""
-    from dirhip.conv import conv2d_igemm
-    tot_flop = tot_ms = 0.0
-    launches = 0
-    per_kind = {}
-    for cin, cout, k, st, h, cnt in RESNET50_CONVS:
-        pad = k // 2
-        ho = (h + 2 * pad - k) // st + 1
-        cfgs = [("fwd", cin, cout, h, st)]
-        if st == 1:
-            cfgs.append(("dgrad", cout, cin, ho, 1))          # same kernel on dY with rotated weights
-        for kind, ci, co, hh, s_ in cfgs:
-            x = torch.randn(batch, ci, hh, hh, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            w = (torch.randn(co, ci, k, k, device=device) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            ms = event_time_ms(lambda: conv2d_igemm(x, w, s_, pad, want_stats=(kind == "fwd")), 5, warm=2)
-            hout = (hh + 2 * pad - k) // s_ + 1
-            flop = 2.0 * batch * hout * hout * co * ci * k * k
-            tot_flop += flop * cnt
-            tot_ms += ms * cnt
-            launches += cnt
-            a = per_kind.setdefault(kind, [0.0, 0.0])
-            a[0] += flop * cnt
-            a[1] += ms * cnt
-            del x, w
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; they come from the separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 98 launches (tools/pmc_conv_pass.py ->
-    # tools/pmc_conv_parse.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/.
-    traffic = traffic_alg = None
-    tpath = os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json")
-    if os.path.isfile(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("batch") == batch and tj.get("launches_per_step") == launches:
-            traffic, traffic_alg = tj["traffic_bytes_per_launch"], tj["algorithmic_bytes_per_step"] / launches
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<128|64> (hand-written MFMA implicit GEMM; all 52 conv layers fwd + 46 stride-1 dgrad)",
-            "achieved": tot_flop / tot_ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": tot_flop / tot_ms / 1e9 / PEAK_BF16_TFLOPS, "traffic": traffic, "algorithmic_bytes_per_launch": traffic_alg,
-            "launches_per_step": launches, "avg_launch_us": tot_ms / launches * 1e3,
-            "algorithmic_flop_per_step": tot_flop, "ms_per_step_in_this_kernel": tot_ms,
-            "fwd_tflops": per_kind["fwd"][0] / per_kind["fwd"][1] / 1e9, "dgrad_tflops": per_kind["dgrad"][0] / per_kind["dgrad"][1] / 1e9}
-
-
-def bn_roofline(device, batch):
-    """Fused BatchNorm(+residual)(+ReLU) forward apply / backward on the widest layer-1 tensor (HBM bound)."""
-    import torch.nn as nn
-    from dirhip.bn import bn_act
-    out = []
-    c, hw = 256, 56
-    x = torch.randn(batch, c, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    r = torch.randn_like(x).requires_grad_(True)
-    dy = torch.randn_like(x)
-    bn = nn.BatchNorm2d(c).to(device)
-    nbytes = x.numel() * 2
-    tf = event_time_ms(lambda: bn_act(x, bn, True, r), 10)
-
-    def fb():
-        bn_act(x, bn, True, r).backward(dy)
-    tb = event_time_ms(fb, 10) - tf
-    for name, ms, passes in (("dir_bn_fwd_train (stats + finalize + apply, residual+ReLU)", tf, 4), ("dir_bn_bwd (reduce + finalize + apply, residual+ReLU)", tb, 8)):
-        out.append({"kernel": name, "bound": "hbm", "shape": f"[{batch},{c},{hw},{hw}] bf16 NHWC", "ms": ms,
-                    "algorithmic_bytes": passes * nbytes, "achieved": passes * nbytes / ms / 1e6, "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": passes * nbytes / ms / 1e6 / PEAK_HBM_GBS})
-    return out
-
-
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle port (torch-CPU restatement of the reference loop) on the host cores: ResNet-50 + FDS + LDS
-    weights + l1 + Adam, B=8 (BASELINE configs[0] batch), epoch tail included every 4 steps."""
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle port (torch-CPU restatement of the reference loop, pinned to the live reference in tests/test_torch_oracle.py)
+    on the host cores: ResNet-50 + FDS + LDS weights + l1 + Adam at B=8 (BASELINE configs[0] batch) with an epoch tail every
+    4 steps, plus the SURVEY §8d micro-baselines of the reference's FDS / loss code path."""
     from oracle import torch_oracle
-    cores = min(os.cpu_count() or 1, int(os.environ.get("DIR_CPU_BASELINE_THREADS", "64")))
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = torch_oracle.RefResNet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
@@ -304,9 +356,43 @@ def cpu_baseline(seconds_budget=25.0):
         if time.perf_counter() - t0 > seconds_budget * 0.6 or steps >= 32:
             break
     dt = time.perf_counter() - t0
-    return {"value": steps * b / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of B={b} 224x224 fp32 + {steps // epoch_len} epoch tails ({epoch_len} fwd passes + FDS update each), "
-                      f"oracle/torch_oracle.py (torch-CPU port of train.py:246-281), {dt:.1f} s"}
+    res = {"value": steps * b / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"{steps} steps of B={b} 224x224 fp32 + {steps // epoch_len} epoch tails ({epoch_len} fwd passes + FDS update each), "
+                     f"oracle/torch_oracle.py (torch-CPU port of train.py:246-281), {dt:.1f} s"}
+    # ---- micro-baselines: the reference's per-label host loops on the CPU
+    def med(fn, n):
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts))
+    micro = []
+    fds = torch_oracle.RefFDS(2048, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9)
+    lab_n = torch.as_tensor(long_tail_labels(np.random.default_rng(5), 50000))
+    feats_n = torch.randn(50000, 2048, generator=g).abs_() * 0.5 + 0.01 * lab_n[:, None]
+    for ep in range(2):
+        fds.update_last_epoch_stats(ep)
+        fds.update_running_stats(feats_n[:20000], lab_n[:20000], ep)
+    t = med(lambda: fds.update_running_stats(feats_n, lab_n, 2), 3)
+    micro.append({"what": "FDS.update_running_stats N=50000 C=2048 (fds.py:84-113)", "ms": t * 1e3, "GB/s": 50000 * 2048 * 4 / t / 1e9})
+    lab_b = torch.as_tensor(long_tail_labels(np.random.default_rng(6), 256)).view(-1, 1)
+
+    def smooth_fb():
+        xb = torch.randn(256, 2048, generator=g).requires_grad_(True)
+        fds.smooth(xb * 1.0, lab_b, 2).sum().backward()
+    smooth_fb()
+    t = med(smooth_fb, 5)
+    micro.append({"what": "FDS.smooth forward + backward B=256 C=2048 (fds.py:115-144)", "ms": t * 1e3})
+    xo, yo, wo = torch.randn(256, 1, generator=g) * 10 + 40, torch.as_tensor(long_tail_labels(rng, 256)).view(-1, 1), torch.rand(256, 1, generator=g) + 0.5
+    for kind in ("mse", "l1", "focal_mse", "focal_l1", "huber"):
+        def lfb(kind=kind):
+            xi = xo.clone().requires_grad_(True)
+            torch_oracle.ref_weighted_loss(kind, xi, yo, wo).backward()
+        lfb()
+        micro.append({"what": f"weighted_{kind}_loss forward + backward B=256 (loss.py)", "ms": med(lfb, 20) * 1e3})
+    res["micro"] = micro
+    return res
 
 
 def main():
@@ -316,7 +402,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--epoch-len", type=int, default=8, help="steps per bench epoch (one FDS epoch tail each)")
-    ap.add_argument("--miopen-find", action="store_true", help="MIOpen find mode (cudnn.benchmark=True like train.py:198)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
@@ -329,17 +414,13 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU (the hot path has no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
-    from dirhip.train_loop import EpochFeatures, resolve_loss
+    from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
     model, engine, optimizer, batches = build(args, device, rank)
     store = EpochFeatures(args.epoch_len * args.batch, 2048, device)
     loss_fn = resolve_loss("l1")
-
     log("model + data built")
-    # set-up, not warm-up: the first step makes the library pick kernels for the few layers still on it (stem conv,
-    # stride-2 data gradients: ~17 s of solver search on a fresh box); one step + one tail forward, untimed
-    from dirhip.train_loop import epoch_tail, train_step
+    # set-up, not warm-up: one step + one tail forward (first-use allocations, weight preparation), untimed
     train_step(engine, optimizer, *batches[0], 2, loss_fn)
     epoch_tail(engine, [(batches[0][0], batches[0][1])], 2, store)
     torch.cuda.synchronize(device)
@@ -364,7 +445,8 @@ def main():
         "value": images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own MFMA kernels: stem, implicit-GEMM fwd/dgrad/wgrad) + fused HIP BatchNorm / join / pool nodes, fp32 FDS+loss tail, "
+        "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own MFMA kernels: stem, "
+                               "implicit-GEMM fwd/dgrad/wgrad) + fused HIP BatchNorm / join / pool nodes, fp32 fused pool-FDS-linear tail + loss, "
                                "batch=256 per MI355X, l1 loss, Adam 1e-3", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "epoch_len_steps": args.epoch_len, "epoch_tails_in_timed_region": n_tails, "parallelism": f"dp{world}",
                    "final_loss": loss_val},
@@ -376,17 +458,76 @@ def main():
                           "train_only_frac": args.steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / PEAK_BF16_TFLOPS},
     }
     result["roofline"] = dict(result["roofline_loop"], traffic=None)      # replaced below by the dominant kernel's when measured
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_kernel_rooflines:
+        fam = in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch)
+        log("in-situ kernel breakdown done")
         del engine, optimizer, batches, store
         torch.cuda.empty_cache()
-        if not args.no_kernel_rooflines:
-            result["roofline"] = conv_roofline(device, args.batch)
-            log("conv roofline done")
-            result["kernel_rooflines"] = kernel_rooflines(device) + bn_roofline(device, args.batch)
-            log("kernel rooflines done")
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
-            log("cpu baseline done")
+        peaks = measured_peaks(device)
+        log("measured peaks done")
+        conv_fwd_flop = conv_flops_per_image() * args.batch
+        busy = sum(f["us_per_step"] for f in fam.values())
+        ig = fam.get("conv_igemm", {"us_per_step": float("nan"), "launches_per_step": 0})
+        alg_flop = 2.0 * conv_fwd_flop                                      # forward + data gradient of the 52 layers
+        ach = alg_flop / (ig["us_per_step"] * 1e-6) / 1e12
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the last counter pass that was
+        # collected (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_conv_pass.py) is quoted with its source
+        traffic_note = None
+        for name in ("r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.isfile(tpath):
+                tj = json.load(open(tpath))
+                traffic_note = {"source": f"profiles/{name}", "traffic_bytes_per_launch": tj.get("traffic_bytes_per_launch"),
+                                "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_step", 0) / max(1, tj.get("launches_per_step", 1)),
+                                "launches_per_step_in_that_pass": tj.get("launches_per_step")}
+                break
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel (hand-written MFMA implicit GEMM): every forward and data-gradient "
+                                       "launch of the 52 conv layers of one training step, in situ",
+            "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+            "frac_of_measured_peak": ach / peaks["bf16_mfma_TFs"], "traffic": None, "traffic_from_profiles": traffic_note,
+            "launches_per_step": ig["launches_per_step"], "avg_launch_us": ig["us_per_step"] / max(1.0, ig["launches_per_step"]),
+            "algorithmic_flop_per_step": alg_flop, "ms_per_step_in_this_kernel": ig["us_per_step"] / 1e3,
+            "method": "device time of every conv_igemm* launch over 4 whole training steps (profiler kernel trace), algorithmic "
+                      "FLOPs = 2 x (forward FLOPs of the 52 layers) = forward + data gradient; SURVEY.md §8d"}
+        result["step_breakdown_in_situ"] = {"busy_ms_per_step": busy / 1e3, "wall_ms_per_step_train_only": dt_train / args.steps * 1e3,
+                                            "families": {k: {"ms_per_step": v["us_per_step"] / 1e3, "launches_per_step": v["launches_per_step"],
+                                                             "share_of_busy": v["us_per_step"] / busy} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us_per_step"])}}
+        kr = []
+        if "conv_wgrad" in fam:
+            a = conv_fwd_flop / (fam["conv_wgrad"]["us_per_step"] * 1e-6) / 1e12
+            kr.append({"kernel": "conv_wgrad_kernel + reduce (weight gradients of the 52 layers), in situ", "bound": "mfma", "ms": fam["conv_wgrad"]["us_per_step"] / 1e3,
+                       "algorithmic_flop": conv_fwd_flop, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_BF16_TFLOPS,
+                       "frac_of_measured_peak": a / peaks["bf16_mfma_TFs"]})
+        if "batchnorm" in fam:
+            # BatchNorm family: forward apply reads y and writes z (2 passes), backward partial reads g, x (2) and apply reads g, x, writes dx (3)
+            # over the 11.11 M BatchNorm-output elements per image in bf16 = 7 passes
+            alg = 7 * 11.11e6 * args.batch * 2
+            a = alg / (fam["batchnorm"]["us_per_step"] * 1e-6) / 1e9
+            kr.append({"kernel": "dir_bn_* family (apply / join / backward partial + apply + finalize), in situ", "bound": "hbm",
+                       "ms": fam["batchnorm"]["us_per_step"] / 1e3, "algorithmic_bytes": alg, "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": a / PEAK_HBM_GBS, "frac_of_measured_peak": a / peaks["stream_copy_GBs"]})
+        if "tail" in fam:
+            alg = 2 * args.batch * 49 * 2048 * 2 + 3 * args.batch * 2048 * 4
+            a = alg / (fam["tail"]["us_per_step"] * 1e-6) / 1e9
+            kr.append({"kernel": "dir_tail_fwd + dir_tail_bwd (pool -> FDS calibrate -> linear), in situ", "bound": "hbm", "ms": fam["tail"]["us_per_step"] / 1e3,
+                       "algorithmic_bytes": alg, "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS})
+        result["kernel_rooflines"] = kr + fds_kernel_rooflines(device)
+        for r in result["kernel_rooflines"]:
+            if r.get("unit") == "GB/s" and "frac_of_measured_peak" not in r:
+                r["frac_of_measured_peak"] = r["achieved"] / peaks["stream_read_GBs"]
+        log("kernel rooflines done")
+        rows = conv_layer_probe(device, args.batch)
+        result["conv_layers"] = {"columns": ["cin", "cout", "k", "stride", "H", "count", "kind", "us", "roofline_us", "launches"],
+                                 "rows": [[*r[:7], round(r[7], 1), round(r[8], 1), r[9]] for r in rows],
+                                 "sum_ms": {kind: sum(r[7] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
+                                 "sum_roofline_ms": {kind: sum(r[8] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
+                                 "note": "isolated launches, inputs rotated over > 256 MB of distinct buffers; roofline_us = max(FLOP / 2.5 PF, bytes / 8 TB/s)"}
+        result["peaks"] = peaks
+        log("conv layer probe done")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

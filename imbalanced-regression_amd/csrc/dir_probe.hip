@@ -11,17 +11,28 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 pb_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float pb_f32x16;
 
+// A workgroup moves 16 KB contiguous blocks (4 x 4 KB wave-rows), blocks dealt round-robin to the workgroups: no
+// power-of-two stride between the loads a lane has in flight (a 8 MB stride parks them all on one HBM channel).
 __global__ void __launch_bounds__(DIR_TPB) probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * DIR_TPB;
-    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    const size_t nblk = n4 / (4 * DIR_TPB);
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
+        const float4 a = src[i], b = src[i + DIR_TPB], c = src[i + 2 * DIR_TPB], d = src[i + 3 * DIR_TPB];
+        dst[i] = a; dst[i + DIR_TPB] = b; dst[i + 2 * DIR_TPB] = c; dst[i + 3 * DIR_TPB] = d;
+    }
+    for (size_t i = nblk * (4 * DIR_TPB) + (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * DIR_TPB) dst[i] = src[i];
 }
 
 __global__ void __launch_bounds__(DIR_TPB) probe_read_kernel(const float4* __restrict__ src, float* __restrict__ out, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * DIR_TPB;
+    const size_t nblk = n4 / (4 * DIR_TPB);
     float acc = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += stride) {
-        const float4 v = src[i];
-        acc += (v.x + v.y) + (v.z + v.w);
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
+        const float4 a = src[i], b = src[i + DIR_TPB], c = src[i + 2 * DIR_TPB], d = src[i + 3 * DIR_TPB];
+        acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+    }
+    for (size_t i = nblk * (4 * DIR_TPB) + (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * DIR_TPB) {
+        const float4 v = src[i]; acc += (v.x + v.y) + (v.z + v.w);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, DIR_WAVE);
@@ -77,7 +88,7 @@ __global__ void __launch_bounds__(DIR_TPB) probe_mfma_f32_kernel(int iters, floa
 
 extern "C" int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, dir_stream_t stream) {
     DIR_RETURN_IF(!src || !dst || bytes < 16 || (bytes & 15) || !dir_aligned16(src) || !dir_aligned16(dst), DIR_EINVAL);
-    hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src),
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(4096), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src),
                        static_cast<float4*>(dst), bytes / 16);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
