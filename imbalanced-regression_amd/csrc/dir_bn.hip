@@ -32,8 +32,8 @@ BnGeom bn_geom(int64_t M, int C) {
     g.rpi = DIR_TPB / g.tpr;
     g.ctiles = C / g.ct;
     int64_t want = (M + (int64_t)g.rpi * 4 - 1) / ((int64_t)g.rpi * 4);   // >= 4 row iterations per workgroup
-    static const int cap_total = []() { const char* e = getenv("DIR_BN_CAP"); return e ? atoi(e) : 768; }();
-    int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768 workgroups = 3 per CU (measured: 256..4096 swept, DIR_BN_CAP), <= 768/ctiles partial rows per channel
+    constexpr int cap_total = 768;                      // workgroups = 3 per CU (256..4096 swept in round 1)
+    int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768/ctiles partial rows per channel
     g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     return g;
 }

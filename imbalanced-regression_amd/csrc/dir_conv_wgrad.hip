@@ -301,10 +301,9 @@ WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
     // Split-K so that the grid fills the chip a whole number of times: `slots` workgroups are resident at once (2 per CU
     // for the 128x128 tile, 3 otherwise: registers / LDS), and a grid slightly above a multiple of that costs a whole
     // extra round. One round measured best (4.99 -> 4.40 ms per ResNet-50 step at batch 256), unless that leaves fewer than
-    // 4 K ranges per tile (512-channel 3x3 layers): then two (DIR_WGRAD_ROUNDS overrides).
-    static const int force_rounds = []() { const char* e = getenv("DIR_WGRAD_ROUNDS"); return e ? atoi(e) : 0; }();
+    // 4 K ranges per tile (512-channel 3x3 layers): then two.
     const int slots = 256 * ((pl.tm == 128 && pl.tn == 128) ? 2 : 3);
-    const int rounds = force_rounds ? force_rounds : (slots / tiles >= 4 ? 1 : 2);
+    const int rounds = slots / tiles >= 4 ? 1 : 2;
     int splits = rounds * slots / tiles;
     int max_splits = pl.ksteps_total / 4; if (max_splits < 1) max_splits = 1;      // >= 4 K-steps per workgroup
     if (splits > max_splits) splits = max_splits;

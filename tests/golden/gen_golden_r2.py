@@ -201,14 +201,54 @@ def gen_validate():
     print("validate:", cases["ref_validate_0"], cases["ref_shot_0"])
 
 
+def gen_nyud2_lds():
+    """nyud2_lds_weights.npz: the reference's depthDataset._get_bucket_weights / get_bin_idx / _get_weights
+    (nyud2-dir/loaddata.py:29-69), compiled out of the file with `ast` (the module imports torchvision at the top)."""
+    import logging
+    from scipy.ndimage import convolve1d
+    path = os.path.join(refshim.REFERENCE_ROOT, "nyud2-dir", "loaddata.py")
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "TRAIN_BUCKET_NUM")
+            or (isinstance(n, ast.ClassDef) and n.name == "depthDataset")]
+    assert len(body) == 2
+    nyu = refshim.load_nyud2()
+    ns = dict(torch=torch, np=np, logging=logging, convolve1d=convolve1d, get_lds_kernel_window=nyu.util.get_lds_kernel_window,
+              Dataset=object, pd=None, os=os)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    cls = ns["depthDataset"]
+    out = {"ref_train_bucket_num": np.asarray(ns["TRAIN_BUCKET_NUM"], dtype=np.int64)}
+    configs = [("sqrt_inv", True, "gaussian", 5, 2), ("inverse", True, "gaussian", 5, 2), ("sqrt_inv", False, "gaussian", 5, 2),
+               ("inverse", False, "gaussian", 5, 2), ("inverse", True, "triang", 9, 1), ("sqrt_inv", True, "laplace", 7, 1.5)]
+    rng = np.random.default_rng(21)
+    depth = rng.uniform(0.0, 10.5, (2, 1, 19, 23)).astype(np.float32)
+    depth[0, 0, 0, :6] = [0.7, 0.69999, 9.9, 9.95, 10.0, 0.0]
+    out["in_depth"] = depth
+    for ci, (rw, lds, k, ks, s) in enumerate(configs):
+        args = types.SimpleNamespace(reweight=rw, lds=lds, lds_kernel=k, lds_ks=ks, lds_sigma=s, bucket_num=100, bucket_start=7)
+        ds = cls.__new__(cls)
+        bw = ds._get_bucket_weights(args)
+        assert all(type(x) is np.float32 for x in bw)
+        ds.bucket_weights = bw
+        out[f"ref_bucket_weights_{ci}"] = np.asarray(bw, dtype=np.float32)
+        out[f"ref_pixel_weights_{ci}"] = ds._get_weights(torch.tensor(depth)).numpy()
+    out["configs"] = np.array([f"{rw},{int(lds)},{k},{ks},{s}" for rw, lds, k, ks, s in configs])
+    ds = cls.__new__(cls)
+    ds.bucket_weights = None
+    out["ref_pixel_weights_none"] = ds._get_weights(torch.tensor(depth)).numpy()
+    np.savez_compressed(os.path.join(HERE, "nyud2_lds_weights.npz"), **out)
+    print("nyud2 lds:", out["ref_bucket_weights_0"][:10])
+
+
 def main():
-    which = sys.argv[1:] or ["step0", "validate"]
+    which = sys.argv[1:] or ["step0", "validate", "nyud2"]
+    if "nyud2" in which:
+        gen_nyud2_lds()
     if "validate" in which:
         gen_validate()
     if "step0" in which:
         gen_step0()
     manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
-                "files": ["step0_b64.npz", "validate.npz"], "generator": "tests/golden/gen_golden_r2.py"}
+                "files": ["step0_b64.npz", "validate.npz", "nyud2_lds_weights.npz"], "generator": "tests/golden/gen_golden_r2.py"}
     with open(os.path.join(HERE, "MANIFEST_r2.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

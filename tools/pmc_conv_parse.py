@@ -13,7 +13,7 @@ for cin, cout, k, st, h, cnt in RESNET50_CONVS:
 out = {"batch": B, "launches_per_step": sum(c for c, _ in cfgs), "algorithmic_bytes_per_step": sum(c * b for c, b in cfgs)}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(sys.argv[1], f"*{name}*counter_collection.csv"))
-    rows = [r for r in csv.DictReader(open(files[0])) if "conv_igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows = [r for r in csv.DictReader(open(files[0])) if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == name]
     vals = [float(r["Counter_Value"]) for r in rows]
     assert len(vals) == 2 * len(cfgs), (len(vals), len(cfgs))
     last = vals[1::2]                                        # second launch of each configuration
@@ -24,5 +24,5 @@ out["hbm_write_bytes_per_step"] = out["WRITE_SIZE_KB_per_step_raw"] * 1024
 out["traffic_bytes_per_step"] = out["hbm_read_bytes_per_step"] + out["hbm_write_bytes_per_step"]
 out["traffic_bytes_per_launch"] = out["traffic_bytes_per_step"] / out["launches_per_step"]
 out["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_conv_pass.py; FETCH_SIZE doubled per MI355X_MICROARCH.md"
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_conv_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_conv_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

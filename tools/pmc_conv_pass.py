@@ -1,6 +1,6 @@
 """One launch of dir_conv_fwd per ResNet-50 conv layer shape (forward + stride-1 dgrad configuration) at batch B, after
 one warm-up launch each — meant to run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes).
-tools/pmc_conv_parse.py turns the counter CSVs into profiles/r01_conv_pmc_traffic.json."""
+tools/pmc_conv_parse.py turns the counter CSVs into profiles/r02_conv_pmc_traffic.json."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
