@@ -46,7 +46,7 @@ struct ConvP {
 };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
-constexpr int CV_DMA_MIN_KT = 36;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+14 % from 36 steps up, slower below 16 (profiles/r02_conv_variants.txt)
+constexpr int CV_DMA_MIN_KT = 32;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+20 % from 32 steps up, mixed at 16, slower below (profiles/r02_conv_variants.txt)
 constexpr int CV_OOB = (int)0x80000000;                         // buffer-load offset beyond any tensor: the load returns zeros
 
 __device__ __forceinline__ uint32_t cv_f2bf(float f) {
@@ -63,27 +63,24 @@ __device__ __forceinline__ uint32_t cv_pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-// Accumulators -> bf16 -> LDS staging tile [128][CS_STRIDE]. C/D layout of the 32x32 MFMA: col = lane & 31,
-// row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): registers e, e+1 of a lane are vertically adjacent elements, so one
-// v_cvt_pk_bf16_f32 converts both and the two halves go out as ds_write_b16 / ds_write_b16_d16_hi to rows r, r+1 -
-// 1.5 instructions per element and no cross-lane traffic (a software round + DPP pair exchange cost ~10).
-// STATS: per-lane sums of the ROUNDED values and their squares (what the following BatchNorm will read).
-template <int MI, int NI, int CS_STRIDE, bool STATS>
-__device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsigned char* cbase, float (&csum)[NI], float (&csq)[NI]) {
+// Accumulators -> bf16 -> LDS staging tile [128 pixels][CS_STRIDE]. The K loops feed the MFMA with the operands SWAPPED
+// (weights as the "A" matrix, pixels as "B"), so an accumulator tile is D'[channel][pixel]: lane l holds pixel (l & 31) and, in
+// registers 4 q .. 4 q + 3, the four CONSECUTIVE channels 8 q + 4 (l >> 5) + {0..3}. Two v_cvt_pk_bf16_f32 make them one 8-byte
+// ds_write_b64: 16 LDS stores per lane for a 64 x 64 wavefront tile instead of the 128 ds_write_b16 of the pixel-major
+// orientation, whose 2048 LDS cycles per workgroup tile (= four K-steps of MFMA time) were the whole cost of the 1-4 step
+// K loops of the 1x1 layers. Row stride 272 / 144 B: consecutive pixels shift 4 banks -> 2-way on the write, rows stay 16-B
+// aligned for the row reads of the store loop.
+template <int MI, int NI, int CS_STRIDE>
+__device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsigned char* cbase) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const uint32_t pk = cv_pack_bf16(acc[mi][ni][e], acc[mi][ni][e + 1]);
-                unsigned char* d = cbase + (mi * 32 + (e & 3) + 8 * (e >> 2)) * CS_STRIDE + ni * 64;
-                *reinterpret_cast<uint16_t*>(d) = (uint16_t)pk;
-                *reinterpret_cast<uint16_t*>(d + CS_STRIDE) = (uint16_t)(pk >> 16);
-                if (STATS) {
-                    const float f0 = __uint_as_float(pk << 16), f1 = __uint_as_float(pk & 0xffff0000u);
-                    csum[ni] += f0 + f1; csq[ni] += f0 * f0 + f1 * f1;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lo = cv_pack_bf16(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1]);
+                const uint32_t hi = cv_pack_bf16(acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+                *reinterpret_cast<uint2*>(cbase + mi * 32 * CS_STRIDE + (ni * 32 + 8 * q) * 2) = make_uint2(lo, hi);
             }
 }
 
@@ -99,31 +96,11 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     const int wm = (BN == 128) ? (wave >> 1) : wave;
     const int wn = (BN == 128) ? (wave & 1) : 0;
     const int frow = lane & 31, fhalf = lane >> 5;
-    constexpr int CS_STRIDE = BN * 2 + 64;                      // bytes per staging row (padding: rows r, r+4 on disjoint banks)
-    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 40 KB)
-    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][64] column partials
-    float csum[NI], csq[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { csum[ni] = 0.0f; csq[ni] = 0.0f; }
-    unsigned char* cbase = Cs + (wm * WM + 4 * fhalf) * CS_STRIDE + (wn * 64 + frow) * 2;
-    if (p.stats) cv_stage_acc<MI, NI, CS_STRIDE, true>(acc, cbase, csum, csq);
-    else cv_stage_acc<MI, NI, CS_STRIDE, false>(acc, cbase, csum, csq);
-    if (p.stats) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            csum[ni] += __shfl_xor(csum[ni], 32, DIR_WAVE);
-            csq[ni] += __shfl_xor(csq[ni], 32, DIR_WAVE);
-            if (fhalf == 0) { Ss[(wave * 2 + 0) * 64 + ni * 32 + frow] = csum[ni]; Ss[(wave * 2 + 1) * 64 + ni * 32 + frow] = csq[ni]; }
-        }
-    }
+    constexpr int CS_STRIDE = BN * 2 + 16;                      // bytes per staging row
+    unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 34 KB)
+    float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][BN] column partials (<= 4 KB)
+    cv_stage_acc<MI, NI, CS_STRIDE>(acc, Cs + (wm * WM + frow) * CS_STRIDE + (wn * 64 + 4 * fhalf) * 2);
     __syncthreads();
-    if (p.stats && t < 2 * BN) {                                // one thread per (which, column)
-        const int which = t / BN, col = t - which * BN;
-        float s = 0.0f;
-        if (BN == 128) { const int w0 = col >> 6; s = Ss[((w0) * 2 + which) * 64 + (col & 63)] + Ss[((w0 + 2) * 2 + which) * 64 + (col & 63)]; }
-        else { s = Ss[(0 * 2 + which) * 64 + col] + Ss[(1 * 2 + which) * 64 + col] + Ss[(2 * 2 + which) * 64 + col] + Ss[(3 * 2 + which) * 64 + col]; }
-        p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = s;
-    }
     constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
     constexpr int RPI = DIR_TPB / CPR;                          // rows per pass of the workgroup
     const int srow = t / CPR, sch = t - srow * CPR;
@@ -131,10 +108,23 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     size_t go = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
     const size_t gstep = (size_t)RPI * p.Cout;
     const bool full = m0 + CV_BM <= p.M;
+    // BatchNorm statistics of the ROUNDED outputs (what the following BatchNorm reads): this thread's 8 channels over the rows
+    // it stores, then over the lanes / wavefronts that share the channel chunk, in a fixed order
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
 #pragma unroll
     for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
         if (full || m0 + srow + i * RPI < p.M) {
             uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+            if (p.stats) {
+                const uint32_t sw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    const float f0 = __uint_as_float(sw[q2] << 16), f1 = __uint_as_float(sw[q2] & 0xffff0000u);
+                    ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
+                }
+            }
             if (p.o2) {                                         // parity class of a stride-2 data gradient: scattered rows
                 const int m = m0 + srow + i * RPI;
                 int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
@@ -187,6 +177,23 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
             *reinterpret_cast<uint4*>(p.y + go) = c;
         }
     }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = CPR; o < DIR_WAVE; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, DIR_WAVE); ssq[j] += __shfl_xor(ssq[j], o, DIR_WAVE); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * BN + lane * 8 + j] = ssum[j]; Ss[(wave * 2 + 1) * BN + lane * 8 + j] = ssq[j]; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {                                       // one thread per (which, column)
+            const int which = t / BN, col = t - which * BN;
+            const float v = (Ss[(0 * 2 + which) * BN + col] + Ss[(1 * 2 + which) * BN + col]) + (Ss[(2 * 2 + which) * BN + col] + Ss[(3 * 2 + which) * BN + col]);
+            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = v;
+        }
+    }
 }
 
 // PF = prefetch distance of the global loads in K-steps. The K loop is bound by load latency, not by MFMA or LDS
@@ -194,7 +201,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
 // rate is (bytes in flight per CU) / latency. PF = 2 keeps two K-tiles per workgroup in flight in two register sets
 // (p, q) for 32 more VGPRs (2 instead of 3 wavefronts per SIMD, which the 64 KB two-stage LDS image allows anyway).
 template <int BN, int PF, int NBUF>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(PF == 1 ? 3 : 2)))
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu((PF == 2 || (NBUF == 2 && BN == 128)) ? 2 : 3)))   // (two 32 KB stages: LDS admits 2 workgroups per CU anyway)
 conv_igemm_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
@@ -331,7 +338,7 @@ conv_igemm_kernel(ConvP p) {
             for (int mi = 0; mi < MI; ++mi)                                                                     \
                 _Pragma("unroll")                                                                               \
                 for (int ni = 0; ni < NI; ++ni)                                                                 \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  /* D'[channel][pixel] */  \
         }                                                                                                       \
     }
 
@@ -350,20 +357,23 @@ conv_igemm_kernel(ConvP p) {
             __syncthreads();
         }
     } else if (PF == 1) {
+        // two K-steps per trip (stages 0 and 1 are literals), whole pairs only, the odd last step peeled off after the loop: a
+        // `break` between the halves gives the loop two exits and the compiler then copies all 64 accumulators every trip
         CV_LOAD_TILE(p);
         CV_STORE_TILE(0, p);
         __syncthreads();
-        for (int kt = 0; kt < p.KT; kt += 2) {                  // two K-steps per trip: stages 0 and 1 are literals
-            if (kt + 1 < p.KT) CV_LOAD_TILE(p);
-            CV_MFMA_STEP(0);
-            if (kt + 1 >= p.KT) break;
+        int kt = 0;
+        for (; kt + 2 <= p.KT; kt += 2) {
+            CV_LOAD_TILE(p);                                    // tile kt + 1
+            CV_MFMA_STEP(0);                                    // tile kt
             CV_STORE_TILE(1, p);
             __syncthreads();
-            if (kt + 2 < p.KT) CV_LOAD_TILE(p);
-            CV_MFMA_STEP(1);
+            if (kt + 2 < p.KT) CV_LOAD_TILE(p);                 // tile kt + 2
+            CV_MFMA_STEP(1);                                    // tile kt + 1
             if (kt + 2 < p.KT) CV_STORE_TILE(0, p);
             __syncthreads();
         }
+        if (kt < p.KT) CV_MFMA_STEP(0);                         // odd K-step count: the last tile sits in stage 0
     } else {
         // PF = 2 (two stages): tiles kt+1 (set q) and kt+2 (set p) are in flight while tile kt is multiplied; a set is
         // re-issued as soon as it has been written to LDS, i.e. two K-steps before it is needed again
@@ -372,14 +382,12 @@ conv_igemm_kernel(ConvP p) {
         CV_STORE_TILE(0, p);
         if (p.KT > 2) CV_LOAD_TILE(p);                          // tile 2
         __syncthreads();
-        for (int kt = 0; kt < p.KT; kt += 2) {
+        int kt = 0;
+        for (; kt + 2 <= p.KT; kt += 2) {
             CV_MFMA_STEP(0);                                    // tile kt
-            if (kt + 1 < p.KT) {
-                CV_STORE_TILE(1, q);                            // tile kt + 1
-                if (kt + 3 < p.KT) CV_LOAD_TILE(q);             // tile kt + 3
-            }
+            CV_STORE_TILE(1, q);                                // tile kt + 1
+            if (kt + 3 < p.KT) CV_LOAD_TILE(q);                 // tile kt + 3
             __syncthreads();
-            if (kt + 1 >= p.KT) break;
             CV_MFMA_STEP(1);                                    // tile kt + 1
             if (kt + 2 < p.KT) {
                 CV_STORE_TILE(0, p);                            // tile kt + 2
@@ -387,8 +395,9 @@ conv_igemm_kernel(ConvP p) {
             }
             __syncthreads();
         }
+        if (kt < p.KT) CV_MFMA_STEP(0);
     }
-    __syncthreads();                                            // (the single/double-stage loops may leave through `break`)
+    __syncthreads();                                            // (every wavefront is done with the K-loop buffers)
 #undef CV_MFMA_STEP
 #undef CV_LOAD_TILE
 #undef CV_STORE_TILE
@@ -524,7 +533,7 @@ conv_igemm_dma_kernel(ConvP p) {
             for (int mi = 0; mi < MI; ++mi)                                                                     \
                 _Pragma("unroll")                                                                               \
                 for (int ni = 0; ni < NI; ++ni)                                                                 \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  /* D'[channel][pixel] */  \
         }                                                                                                       \
     }
 
@@ -538,13 +547,20 @@ conv_igemm_dma_kernel(ConvP p) {
 
     CV_ISSUE_TILE(0);
     __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
-    for (int kt = 0; kt < p.KT; kt += 2) {                      // two K-steps per trip: stages 0 and 1 are literals
-        if (kt + 1 < p.KT) CV_ISSUE_TILE(1);
-        CV_MFMA_STEP(0);
+    // Two K-steps per trip (stages 0 and 1 are literals), whole pairs only and the odd last step peeled off AFTER the loop:
+    // a `break` between the two halves gives the loop two exits and makes the compiler carry a second copy of the 64
+    // accumulators through v_accvgpr_read / v_accvgpr_write (138 extra VALU per 32 MFMAs, each waiting for its MFMA).
+    int kt = 0;
+    for (; kt + 2 <= p.KT; kt += 2) {
+        CV_ISSUE_TILE(1);                                       // tile kt + 1
+        CV_MFMA_STEP(0);                                        // tile kt
         __syncthreads();
-        if (kt + 1 >= p.KT) break;
-        if (kt + 2 < p.KT) CV_ISSUE_TILE(0);
-        CV_MFMA_STEP(1);
+        if (kt + 2 < p.KT) CV_ISSUE_TILE(0);                    // tile kt + 2
+        CV_MFMA_STEP(1);                                        // tile kt + 1
+        __syncthreads();
+    }
+    if (kt < p.KT) {                                            // odd K-step count: the last tile sits in stage 0
+        CV_MFMA_STEP(0);
         __syncthreads();
     }
 #undef CV_MFMA_STEP
@@ -662,7 +678,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // 1 (43 KB, 3 per CU, one extra barrier) when the loop is short and the layer is bound by memory latency; prefetch
     // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int bn = wide ? 128 : 64;
-    const int stage = CV_BM * (bn * 2 + 64) + 2048;                 // epilogue staging + column partials
+    const int stage = CV_BM * (bn * 2 + 16) + 4 * 2 * bn * 4;      // epilogue staging + column partials
     const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
     if (dma) {
         const int loop2 = 2 * (CV_BM * CV_ROWB + bn * CV_ROWB);

@@ -228,10 +228,13 @@ conv_wgrad_kernel(WgP p) {
         WG_LOAD(ks0);
         WG_STORE(0);
         __syncthreads();
-        for (int ks = ks0; ks < ks1; ks += 2) {                  // two K-steps per trip: stages 0 and 1 are literals
-            if (ks + 1 < ks1) WG_LOAD(ks + 1);                   // global loads in flight during the MFMAs
+        // two K-steps per trip (stages 0 and 1 are literals), whole pairs only, the odd last step peeled off after the loop:
+        // a `break` between the halves gives the loop two exits, and the compiler then copies all accumulators (32 v_mov_b64
+        // per 16 MFMAs, each waiting for its MFMA chain) on every trip
+        int ks = ks0;
+        for (; ks + 2 <= ks1; ks += 2) {
+            WG_LOAD(ks + 1);                                     // global loads in flight during the MFMAs
             WG_MFMA_STEP(0);
-            if (ks + 1 >= ks1) break;
             WG_STORE(1);
             __syncthreads();
             if (ks + 2 < ks1) WG_LOAD(ks + 2);
@@ -239,6 +242,7 @@ conv_wgrad_kernel(WgP p) {
             if (ks + 2 < ks1) WG_STORE(0);
             __syncthreads();
         }
+        if (ks < ks1) WG_MFMA_STEP(0);                           // odd K-step count: the last tile sits in stage 0
     }
 #undef WG_BL
 #undef WG_LOAD
