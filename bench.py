@@ -178,6 +178,8 @@ def measured_peaks(device):
     out["stream_copy_GBs"] = 2 * nbytes / ms / 1e6
     ms = event_time_ms(lambda i: L.check(lib.dir_probe_stream_read(L.ptr(src), L.ptr(red), nbytes, st), "read"), 10)
     out["stream_read_GBs"] = nbytes / ms / 1e6
+    ms = event_time_ms(lambda i: L.check(lib.dir_probe_stream_write(L.ptr(dst), nbytes, st), "write"), 10)
+    out["stream_write_GBs"] = nbytes / ms / 1e6
     del src, dst
     wgs = 256 * 8
     buf = torch.empty(wgs * 256, dtype=torch.float32, device=device)

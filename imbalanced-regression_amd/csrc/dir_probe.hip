@@ -3,6 +3,7 @@
 // and prints the results next to the nominal peaks of MI355X_MICROARCH.md.
 //   dir_probe_stream_copy : float4 copy, 16 B per lane, grid-stride from 2048 workgroups  -> achievable HBM bytes/s
 //   dir_probe_stream_read : same loads, wave-reduced, one store per workgroup             -> achievable HBM read bytes/s
+//   dir_probe_stream_write: stores only (16 KB blocks)                                    -> achievable HBM write bytes/s
 //   dir_probe_mfma_bf16   : 8 independent v_mfma_f32_32x32x16_bf16 accumulator chains per wavefront, no memory traffic
 //   dir_probe_mfma_f32    : the same with v_mfma_f32_32x32x2_f32 (the exact-f32 matrix path of the parity mode)
 #include "dir_common.h"
@@ -37,6 +38,15 @@ __global__ void __launch_bounds__(DIR_TPB) probe_read_kernel(const float4* __res
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, DIR_WAVE);
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
+
+__global__ void __launch_bounds__(DIR_TPB) probe_write_kernel(float4* __restrict__ dst, size_t n4, float v) {
+    const size_t nblk = n4 / (4 * DIR_TPB);
+    const float4 x = make_float4(v, v + 1.0f, v + 2.0f, v + 3.0f);
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
+        dst[i] = x; dst[i + DIR_TPB] = x; dst[i + 2 * DIR_TPB] = x; dst[i + 3 * DIR_TPB] = x;
+    }
 }
 
 template <int CHAINS>
@@ -97,6 +107,13 @@ extern "C" int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, d
 extern "C" int dir_probe_stream_read(const void* src, float* out /* >= 8192 floats */, size_t bytes, dir_stream_t stream) {
     DIR_RETURN_IF(!src || !out || bytes < 16 || (bytes & 15) || !dir_aligned16(src), DIR_EINVAL);
     hipLaunchKernelGGL(probe_read_kernel, dim3(2048), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src), out, bytes / 16);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_probe_stream_write(void* dst, size_t bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dst || bytes < 16384 || (bytes & 16383) || !dir_aligned16(dst), DIR_EINVAL);
+    hipLaunchKernelGGL(probe_write_kernel, dim3(4096), dim3(DIR_TPB), 0, dir_s(stream), static_cast<float4*>(dst), bytes / 16, 1.0f);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "dir_tail_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_probe_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_probe_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_probe_stream_write": (c_int, [c_void_p, c_size_t, c_void_p]),
     "dir_probe_mfma_bf16": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_probe_mfma_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -430,10 +430,12 @@ int dir_tail_bwd(const float* dpred, const float* dencoding, const int32_t* bins
  * next to the nominal 8 TB/s / 2.5 PFLOP/s).  Not part of the reference's path; bench.py times them with HIP events.
  *   dir_probe_stream_copy: dst[i] = src[i], 16 B per lane, 2048 workgroups grid-stride  (moves 2 * bytes)
  *   dir_probe_stream_read: read-only stream, wave-reduced, out >= 8192 floats           (moves bytes)
+ *   dir_probe_stream_write: write-only stream                                           (moves bytes)
  *   dir_probe_mfma_bf16 / _f32: `iters` rounds of independent MFMA chains per wavefront, no memory traffic;
  *                          *flops (host, nullable) receives the FLOPs of the launch; out >= workgroups * 256 floats. */
 int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, dir_stream_t stream);
 int dir_probe_stream_read(const void* src, float* out, size_t bytes, dir_stream_t stream);
+int dir_probe_stream_write(void* dst, size_t bytes, dir_stream_t stream);        /* write-only stream; bytes % 16384 == 0 */
 int dir_probe_mfma_bf16(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
 int dir_probe_mfma_f32(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
 

@@ -41,6 +41,8 @@ def measure(device=None):
     out["stream_copy_GBs"] = 2 * nbytes / ms / 1e6
     ms = ev(lambda: L.check(lib.dir_probe_stream_read(L.ptr(src), L.ptr(red), nbytes, st), "read"), 10)
     out["stream_read_GBs"] = nbytes / ms / 1e6
+    ms = ev(lambda: L.check(lib.dir_probe_stream_write(L.ptr(dst), nbytes, st), "write"), 10)
+    out["stream_write_GBs"] = nbytes / ms / 1e6
     del src, dst
     wgs = 256 * 8                                     # 8 workgroups of 4 wavefronts per CU = 8 wavefronts per SIMD (2 resident rounds)
     buf = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
