@@ -404,17 +404,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--epoch-len", type=int, default=8, help="steps per bench epoch (one FDS epoch tail each)")
+    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"], help="torch.distributed backend (default: nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo), to run the N > 1 "
+                    "control flow on a one-GPU box; the throughput it prints is meaningless")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
     args.epoch_len = max(1, min(args.epoch_len, args.steps))      # at least one epoch tail inside the timed region
     from dirhip.parallel import init_distributed
-    rank, world, local_rank = init_distributed()
+    rank, world, local_rank = init_distributed(backend=args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the hot path has no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(device)
 
     from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
@@ -446,7 +449,7 @@ def main():
         "metric": "images/sec ResNet-50+FDS IMDB-WIKI 224x224 (train loop incl. FDS epoch tail)",
         "value": images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16", "data": "synthetic" if not args.share_gpu else "synthetic (TEST RUN: all ranks share one GPU, number meaningless)",
         "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own MFMA kernels: stem, "
                                "implicit-GEMM fwd/dgrad/wgrad) + fused HIP BatchNorm / join / pool nodes, fp32 fused pool-FDS-linear tail + loss, "
                                "batch=256 per MI355X, l1 loss, Adam 1e-3", "per_gpu_batch": args.batch, "global_batch": args.batch * world,

@@ -293,3 +293,24 @@ def test_two_rank_train_steps_equal_single_process_emulation(tmp_path):
     # each rank's BatchNorm statistics are those of ITS half (no SyncBN in the reference)
     assert_close(m0["bn1.running_mean"].numpy(), replicas[0].state_dict()["bn1.running_mean"].cpu().numpy(), rtol=1e-5, atol_scale=1e-6)
     assert_close(m1["bn1.running_mean"].numpy(), replicas[1].state_dict()["bn1.running_mean"].cpu().numpy(), rtol=1e-5, atol_scale=1e-6)
+
+
+def test_bench_multi_rank_control_flow_two_processes_one_gpu(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2 ...), except that both ranks share the one GPU over gloo (--backend gloo --share-gpu): barrier + MAX-over-ranks
+    timing, per-rank batches, gradient buckets from the real fused nodes, the FDS statistic merge in the epoch tail, one JSON
+    line from rank 0 with the whole-job aggregate. (RCCL itself cannot run here: the lease has one GPU.)"""
+    import json
+    port = 36000 + int(np.random.default_rng().integers(0, 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "16",
+           "--epoch-len", "2", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-kernel-rooflines"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                                  # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 2 and r["scaling"] == "weak" and r["unit"] == "images/sec"
+    assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp2" and r["config"]["epoch_tails_in_timed_region"] == 2
+    assert abs(r["value"] - 4 * 16 * 2 / (r["ms_per_step"] * 4 / 1e3)) <= 1e-6 * r["value"]     # whole-job aggregate over both ranks
+    assert np.isfinite(r["config"]["final_loss"])
