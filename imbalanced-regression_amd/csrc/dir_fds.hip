@@ -76,7 +76,7 @@ extern "C" int dir_fds_bin_index(const float* labels, int n, int bucket_start, i
 //           float64 registers around the shift K = first row of the bin;
 // Stage C : pieces of a bin are combined in index order -> (count, mean, M2).
 #define GROUP_TILE 256        // rows per grouping wavefront: N / 256 wavefronts keep all 256 CUs busy at N = 191 509
-#define PIECE_ROWS 128
+#define PIECE_ROWS 256        // rows per piece: 2 x fewer float64 partials to write and re-read than 128 (52 -> 26 MB at N = 191 509)
 #define PIECE_UNROLL 8
 
 struct ScatterWs {            // carved from the caller's workspace (all 256-B aligned)
@@ -178,10 +178,12 @@ fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
     extern __shared__ __attribute__((aligned(16))) int32_t sh[];     // totals[nb+1], pieces[nb+1]
     int32_t* tot = sh;
     int32_t* pcs = sh + (nb + 1);
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) pcs[b] = totals[b];     // parallel fetch: the serial scan below then runs on LDS
+    __syncthreads();
     if (threadIdx.x == 0) {                                // nb is a few hundred at most
         int o = 0, p = 0;
         for (int b = 0; b < nb; ++b) {
-            const int c = totals[b];
+            const int c = pcs[b];
             offsets[b] = o; bin_piece0[b] = p;
             tot[b] = o; pcs[b] = p;
             o += c; p += (c + PIECE_ROWS - 1) / PIECE_ROWS;
@@ -199,9 +201,13 @@ fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
     }
 }
 
-// G3: one wavefront per tile; stable placement through ballots.
+// G3: one wavefront per tile; stable placement. For each chunk of 64 rows the lanes that share a bin are found with one
+// ballot per BIT of the bin index ("match-any": 7 ballots for 100 bins, no loop over the distinct bins of the chunk, no
+// barrier), the lowest such lane bumps the bin's cursor once (LDS atomic of ONE lane per bin and chunk, chunks in program
+// order: the result is the stable order, independent of timing) and every lane stores its row at base + (number of lower
+// lanes of its bin). Round 1 looped over the distinct bins of a chunk with two barriers each: 22-27 us, latency bound.
 __global__ void __launch_bounds__(DIR_WAVE)
-fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb,
+fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbits,
                        const int32_t* __restrict__ tile_prefix, const int32_t* __restrict__ offsets,
                        int32_t* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) int32_t cursor[];
@@ -214,17 +220,19 @@ fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb,
         const int r = r0 + c + lane;
         int b = (r < n) ? bins[r] : -1;
         if (b >= nb) b = -1;
-        unsigned long long todo = __ballot(b >= 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int b0 = __shfl(b, leader, DIR_WAVE);
-            const unsigned long long mask = __ballot(b == b0);
-            const int base = cursor[b0];
-            __syncthreads();                               // all lanes have read before the bump
-            if (b == b0) perm[base + __popcll(mask & lt)] = r;
-            if (lane == leader) cursor[b0] = base + __popcll(mask);
-            __syncthreads();
-            todo &= ~mask;
+        const bool valid = b >= 0;
+        unsigned long long mask = __ballot(valid);
+        for (int k = 0; k < nbits; ++k) {
+            const bool bit = valid && ((b >> k) & 1);
+            const unsigned long long m = __ballot(bit);
+            mask &= bit ? m : ~m;
+        }
+        if (valid) {                                            // mask = the valid lanes of this chunk with my bin
+            const int leader = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[b], __popcll(mask));
+            base = __shfl(base, leader, DIR_WAVE);
+            perm[base + __popcll(mask & lt)] = r;
         }
         if (r0 + c + DIR_WAVE >= n) break;
     }
@@ -346,7 +354,16 @@ fds_combine_kernel(const float* __restrict__ feats, int C, int nb,
     const size_t o = (size_t)b * C + col;
     if (cnt == 0) { mean[o] = 0.0; m2[o] = 0.0; return; }
     double s1 = 0.0, s2 = 0.0;
-    for (int k = bin_piece0[b]; k < bin_piece0[b + 1]; ++k) {
+    const int k1 = bin_piece0[b + 1];
+    int k = bin_piece0[b];
+    for (; k + 4 <= k1; k += 4) {                           // 8 independent loads in flight; summed in piece order
+        double a[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = partials[((size_t)(k + u) * 2 + 0) * C + col]; q[u] = partials[((size_t)(k + u) * 2 + 1) * C + col]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += a[u]; s2 += q[u]; }
+    }
+    for (; k < k1; ++k) {
         s1 += partials[((size_t)k * 2 + 0) * C + col];
         s2 += partials[((size_t)k * 2 + 1) * C + col];
     }
@@ -386,8 +403,10 @@ extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t
                        w.totals, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
                        w.piece_bin, w.piece_p0, w.piece_p1);
     DIR_LAUNCH_CHECK();
+    int nbits = 0;
+    while ((1 << nbits) < nb) ++nbits;
     hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s,
-                       bins, n, nb, w.tile_hist, w.offsets, w.perm);
+                       bins, n, nb, nbits, w.tile_hist, w.offsets, w.perm);
     DIR_LAUNCH_CHECK();
     const bool vec4 = (C % 4 == 0) && dir_aligned16(feats);
     const int tpr = C / 4;
@@ -570,13 +589,15 @@ fds_calibrate_fwd_kernel(float* __restrict__ x, const int32_t* __restrict__ bins
     if (VEC == 4) {
         const int col = (blockIdx.y * DIR_TPB + threadIdx.x) * 4;
         if (col >= C) return;
-        float4 v = *reinterpret_cast<float4*>(x + xo + col);
+        // the row is streamed (non-temporal: read once, written once) so that the three [Nb, C] tables stay L2 resident
+        typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+        f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + xo + col));
         const float4 a = *reinterpret_cast<const float4*>(m1 + to + col);
         const float4 s = *reinterpret_cast<const float4*>(scale + to + col);
         const float4 c = *reinterpret_cast<const float4*>(m2 + to + col);
         v.x = calib1(v.x, a.x, s.x, c.x); v.y = calib1(v.y, a.y, s.y, c.y);
         v.z = calib1(v.z, a.z, s.z, c.z); v.w = calib1(v.w, a.w, s.w, c.w);
-        *reinterpret_cast<float4*>(x + xo + col) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(x + xo + col));
     } else {
         const int col = blockIdx.y * DIR_TPB + threadIdx.x;
         if (col >= C) return;

@@ -319,6 +319,49 @@ def test_full_size_smooth_identity_and_linearity():
     assert_close(ones.cpu().numpy(), np.full((100, 2048), 3.0), rtol=1e-6, atol_scale=1e-6)
 
 
+def test_full_size_smooth_bit_equal_oracle():
+    """BASELINE.json's training shape (B=256 rows x 2048 features, 100 bins): smooth() forward and backward bit-for-bit
+    against the oracle (fds.py:115-144) when both hold the SAME tables. The tables come from the oracle's own two epochs
+    of update_running_stats / update_last_epoch_stats over realistic features (post-ReLU, per-channel scale spread), so the
+    calibration runs on non-trivial means / variances, with zero-variance channels (A.9 guard: v1 == 0 -> untouched),
+    factors clipped at 10 (the 5-tap window keeps >= 0.25 of a bin's own variance, so 0.1 is unreachable with ks=5) and
+    bins the batch never visits."""
+    from dirhip.fds import FDS
+    rng = np.random.default_rng(20260924)
+    C, NB = 2048, 100
+    O = fds_oracle.FDSOracle(C)
+    chan_scale = np.exp(rng.normal(0.0, 1.0, C)).astype(np.float32)
+    chan_scale[::97] = 0.0                                           # dead channels -> variance exactly 0
+    for epoch in range(2):
+        n = 6000
+        labels = np.clip(np.round(rng.gamma(4.0, 8.0, n)), 0, 120).astype(np.float32)
+        labels[labels > 95] = 95                                     # bins 96.. stay at their initial (0, 1) rows
+        feats = np.maximum(rng.normal(0.2, 1.0, (n, C)).astype(np.float32) * chan_scale * (1 + labels[:, None] / 60), 0)
+        feats[:, 5::211] *= np.where(labels[:, None] % 2 == 0, 30.0, 0.02).astype(np.float32)   # odd bins: factor clips at 10
+        O.update_last_epoch_stats(epoch)
+        O.update_running_stats(feats, labels, epoch)
+    O.update_last_epoch_stats(2)
+    F = FDS(C).cuda()
+    for k in BUFFERS:
+        getattr(F, k).copy_(dev(np.ascontiguousarray(getattr(O, k))))
+    F._invalidate()
+    B = 256
+    lab = np.clip(np.round(rng.gamma(4.0, 8.0, (B, 1))), 0, 120).astype(np.float32)
+    lab[:4, 0] = (0.0, 99.0, 120.0, 97.0)                            # edge bins, incl. the clamp at the top (utils / fds.py:119-123)
+    x = np.maximum(rng.normal(0.2, 1.0, (B, C)), 0).astype(np.float32) * chan_scale
+    gy = rng.normal(0, 1, (B, C)).astype(np.float32)
+    s = np.stack([fds_oracle.calibrate_scale(O.running_var_last_epoch[b], O.smoothed_var_last_epoch[b]) for b in range(NB)])
+    assert (s < 0).any() and (s == np.sqrt(np.float32(10.0))).any() and ((s > 0.5) & (s < 3.0)).any()
+    xt = dev(x).requires_grad_(True)
+    y = F.smooth(xt.clone(), dev(lab), 2)
+    y.backward(dev(gy))
+    yo = O.smooth(x.copy(), lab, 2)
+    go = O.smooth_grad(gy, lab, 2)
+    assert not np.array_equal(yo, x)
+    assert np.array_equal(y.detach().cpu().numpy(), yo)
+    assert np.array_equal(xt.grad.cpu().numpy(), go)
+
+
 # ---------------------------------------------------------------------------------------------------
 # STS-B FDS variant (SURVEY.md §8f-2): histogram-edge buckets, clip [0.5, 2] with v1 <= 0 / v2 < 0 guards,
 # empty-bucket fill — vs the reference's own outputs (golden) and the oracle
