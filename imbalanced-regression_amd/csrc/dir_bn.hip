@@ -346,14 +346,14 @@ bn_bwd_partial_kernel(const T* __restrict__ dout, const T* __restrict__ x, const
 
 // dbeta = sum g;  dgamma = rstd * (sum g*x - mean * sum g);  dx = a*g + p*x + q with
 // a = gamma*rstd, p = -a*rstd*dgamma/M, q = -a*dbeta/M - p*mean.   coef: [0]=a [1]=p [2]=q
-template <int FC>
+template <int FC, typename PT>
 __global__ void __launch_bounds__(DIR_TPB)
-bn_bwd_finalize_kernel(const float* __restrict__ partial, int rblocks, int64_t M, int C,
+bn_bwd_finalize_kernel(const PT* __restrict__ partial, int rblocks, int64_t M, int C,
                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
                        const float* __restrict__ save_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                        float* __restrict__ coef) {
     double sg, sgx;
-    if (!column_sums<FC, float>(partial, rblocks, C, sg, sgx)) return;
+    if (!column_sums<FC, PT>(partial, rblocks, C, sg, sgx)) return;
     const int c = blockIdx.x * FC + threadIdx.x;
     const double mean = (double)save_mean[c], rstd = (double)save_rstd[c], n = (double)M;
     const double dg = rstd * (sgx - mean * sg);
@@ -518,7 +518,7 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
 template <typename T>
 int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, void* dres_, int64_t M, int C,
              const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, float* dgamma,
-             float* dbeta, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+             float* dbeta, int relu, void* ws, size_t ws_bytes, hipStream_t s, const float* ext_partial = nullptr, int ext_rows = 0) {
     constexpr int VEC = Vec<T>::N;
     const T* dout = static_cast<const T*>(dout_); const T* x = static_cast<const T*>(x_); const T* out = static_cast<const T*>(out_);
     T* dx = static_cast<T*>(dx_); T* dres = static_cast<T*>(dres_);
@@ -529,13 +529,35 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     const BnMaskCoef mc{gamma, beta, save_mean, save_rstd};
     // mask source: saved output if given, else recomputed from x (only valid when no residual was added)
     const int mask = !relu ? 0 : (out ? 1 : 2);
-    if (mask == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 1>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
-    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 2>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 0>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
-    DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(dir_cdiv(C, 8)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
-                       save_mean, save_rstd, dgamma, dbeta, w.coef);
-    DIR_LAUNCH_CHECK();
+    if (ext_partial) {
+        // the first pass ran inside the data-gradient kernel that produced dout (dir_conv_dgrad_bnstats): one row of partials per
+        // 128-pixel tile; long lists are folded to <= 32 rows of doubles first (as in the forward, prepare_impl)
+        DIR_RETURN_IF(mask == 1, DIR_EINVAL);
+        int splits = ext_rows / 64;
+        if (splits > 32) splits = 32;
+        if (splits > g.rblocks / 2) splits = g.rblocks / 2;
+        if (splits >= 4) {
+            const int rps = dir_cdiv(ext_rows, splits);
+            splits = dir_cdiv(ext_rows, rps);
+            double* folded = reinterpret_cast<double*>(w.partial);
+            hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3(dir_cdiv(C, 8), splits), blk, 0, s, ext_partial, ext_rows, C, rps, folded);
+            DIR_LAUNCH_CHECK();
+            hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, double>), dim3(dir_cdiv(C, 8)), blk, 0, s, folded, splits, M, C, gamma,
+                               save_mean, save_rstd, dgamma, dbeta, w.coef);
+        } else {
+            hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), blk, 0, s, ext_partial, ext_rows, M, C, gamma,
+                               save_mean, save_rstd, dgamma, dbeta, w.coef);
+        }
+        DIR_LAUNCH_CHECK();
+    } else {
+        if (mask == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 1>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+        else if (mask == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 2>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+        else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 0>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+        DIR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), blk, 0, s, w.partial, g.rblocks, M, C, gamma,
+                           save_mean, save_rstd, dgamma, dbeta, w.coef);
+        DIR_LAUNCH_CHECK();
+    }
     if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
     else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
     else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
@@ -617,6 +639,25 @@ extern "C" int dir_bn_bwd(const void* dout, const void* x, const void* out, void
                            workspace, workspace_bytes, dir_s(stream));
 }
 
+// dir_bn_bwd whose first pass (the per-channel sums of g and g*x) already ran inside the data-gradient kernel that produced
+// dout (dir_conv_dgrad_bnstats / dir_conv_dgrad_s2_bnstats): `partial` = its [partial_rows][2][C] output. relu != 0: the ReLU
+// mask is recomputed from x in the apply pass (no residual); a mask from a saved output is not a case of this entry point.
+extern "C" int dir_bn_bwd_partials(const void* dout, const void* x, void* dx, int dtype, int64_t M, int C, const float* gamma,
+                                   const float* beta, const float* save_mean, const float* save_rstd, float* dgamma,
+                                   float* dbeta, int relu, const float* partial, int partial_rows, void* workspace,
+                                   size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dout || !x || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(!partial || partial_rows <= 0 || (relu && !beta), DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(dout) || !dir_aligned16(x) || !dir_aligned16(dx), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return bwd_impl<bf16_t>(dout, x, nullptr, dx, nullptr, M, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, relu,
+                                workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
+    return bwd_impl<float>(dout, x, nullptr, dx, nullptr, M, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, relu,
+                           workspace, workspace_bytes, dir_s(stream), partial, partial_rows);
+}
+
 extern "C" int dir_bn_prepare_train(const void* x, int dtype, int64_t M, int C, const float* partial, int partial_rows,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     double momentum, double eps, float* save_mean, float* save_rstd, float* coef,
@@ -647,7 +688,7 @@ extern "C" int dir_bn_apply(const void* x, const void* residual, const float* re
 extern "C" int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
                                    const float* save_rstd, float* dgamma, float* dbeta, float* coef, dir_stream_t stream) {
     DIR_RETURN_IF(!partial || rows <= 0 || M <= 0 || C <= 0 || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !coef, DIR_EINVAL);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, dir_s(stream), partial, rows, M, C, gamma,
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), dim3(DIR_TPB), 0, dir_s(stream), partial, rows, M, C, gamma,
                        save_mean, save_rstd, dgamma, dbeta, coef);
     DIR_LAUNCH_CHECK();
     return DIR_OK;

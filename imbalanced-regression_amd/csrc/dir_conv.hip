@@ -43,7 +43,14 @@ struct ConvP {
     int o2, o_a, o_b, OH, OW; // o2: output row (n, i, j) is stored at pixel (2 i + o_a, 2 j + o_b) of an [N][OH][OW][Cout] tensor
                               // (one parity class of a stride-2 data gradient); else rows are stored densely
     int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
+    // BatchNorm-backward reduction fused into a data-gradient store loop: this launch's result is the gradient of the OUTPUT of a
+    // BatchNorm whose input is bnx (same [rows][Cout] geometry as y); `stats` then receives the per-tile partials (sum g, sum g*bnx)
+    // of dir_bn_bwd's first pass. With bn_gamma: that BatchNorm is followed by a ReLU whose mask (bnx * a + b > 0, the forward's own
+    // decision) is applied to g for the sums only (the stored gradient stays unmasked: the BatchNorm's apply pass masks it again).
+    const uint16_t* bnx;
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_rstd;
 };
+struct ConvBn { const void* x; const float* gamma; const float* beta; const float* mean; const float* rstd; };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
 constexpr int CV_DMA_MIN_KT = 32;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+20 % from 32 steps up, mixed at 16, slower below (profiles/r02_conv_variants.txt)
@@ -113,11 +120,39 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     float ssum[8], ssq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+    const bool fwd_stats = p.stats && !p.bnx;
+    // fused BatchNorm-backward partials: (sum g, sum g * bnx) of the gradient as stored, optionally under the recomputed ReLU mask
+    float maf[8], mbf[8];
+    if (p.bnx && p.bn_gamma) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                           // same expression as dir_bn.hip's bn_mask_coef (= the forward's coefficients)
+            const int ch = n0 + sch * 8 + j;
+            const double gm = (double)p.bn_gamma[ch], rs = (double)p.bn_rstd[ch];
+            maf[j] = (float)(gm * rs);
+            mbf[j] = (float)((double)p.bn_beta[ch] - (double)p.bn_mean[ch] * gm * rs);
+        }
+    }
+#define CV_BN_ACC(cvec, xptr)                                                                                   \
+    {                                                                                                           \
+        const uint4 xv = *reinterpret_cast<const uint4*>(xptr);                                                 \
+        const uint32_t gw[4] = {(cvec).x, (cvec).y, (cvec).z, (cvec).w};                                        \
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};                                                        \
+        _Pragma("unroll")                                                                                       \
+        for (int q2 = 0; q2 < 4; ++q2) {                                                                        \
+            float g0 = __uint_as_float(gw[q2] << 16), g1 = __uint_as_float(gw[q2] & 0xffff0000u);              \
+            const float x0 = __uint_as_float(xw[q2] << 16), x1 = __uint_as_float(xw[q2] & 0xffff0000u);        \
+            if (p.bn_gamma) {                                                                                   \
+                if (!(x0 * maf[2 * q2] + mbf[2 * q2] > 0.0f)) g0 = 0.0f;                                        \
+                if (!(x1 * maf[2 * q2 + 1] + mbf[2 * q2 + 1] > 0.0f)) g1 = 0.0f;                                \
+            }                                                                                                   \
+            ssum[2 * q2] += g0; ssq[2 * q2] += g0 * x0; ssum[2 * q2 + 1] += g1; ssq[2 * q2 + 1] += g1 * x1;     \
+        }                                                                                                       \
+    }
 #pragma unroll
     for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
         if (full || m0 + srow + i * RPI < p.M) {
             uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
-            if (p.stats) {
+            if (fwd_stats) {
                 const uint32_t sw[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
                 for (int q2 = 0; q2 < 4; ++q2) {
@@ -133,6 +168,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                 if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
                 const size_t orow = ((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b;
                 *reinterpret_cast<uint4*>(p.y + orow * p.Cout + n0 + sch * 8) = c;
+                if (p.bnx) CV_BN_ACC(c, p.bnx + orow * p.Cout + n0 + sch * 8);
                 continue;
             }
             if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
@@ -175,8 +211,10 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                 c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
             }
             *reinterpret_cast<uint4*>(p.y + go) = c;
+            if (p.bnx) CV_BN_ACC(c, p.bnx + go);
         }
     }
+#undef CV_BN_ACC
     if (p.stats) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -584,7 +622,7 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
                        dir_stream_t stream);
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                          int cls_a, int cls_b, int variant, dir_stream_t stream);
+                          int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn = nullptr);
 
 extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
                                 int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
@@ -616,18 +654,46 @@ extern "C" int dir_conv_dgrad_join(const void* x, const void* w, const void* add
     return conv_launch(x, w, addend, addend_s2, relu_mask, y, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, stream);
 }
 
-extern "C" int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
-                                 dir_stream_t stream) {
+static int conv_dgrad_s2_impl(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                              const ConvBn* bn, float* stats, dir_stream_t stream) {
     DIR_RETURN_IF(!dy || !wcls || !dx, DIR_EINVAL);
     // classes (a, b) in the order (0,0) (0,1) (1,0) (1,1): 1, 2, 2, 4 filter taps, packed back to back as [Cx][taps][Cy]
     static const int tap_base[4] = {0, 1, 3, 5};
+    const size_t rows = dir_conv_stats_rows(N, Ho, Wo);              // partial rows per class (fused BatchNorm-backward sums)
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
             const uint16_t* wc = static_cast<const uint16_t*>(wcls) + (size_t)tap_base[a * 2 + b] * Cx * Cy;
-            const int rc = conv_launch_ex(dy, wc, nullptr, nullptr, nullptr, dx, nullptr, N, Ho, Wo, Cy, Cx, 1 + a, 1 + b, 1, 0, a, b, 0, stream);
+            float* st = stats ? stats + (size_t)(a * 2 + b) * rows * 2 * Cx : nullptr;
+            const int rc = conv_launch_ex(dy, wc, nullptr, nullptr, nullptr, dx, st, N, Ho, Wo, Cy, Cx, 1 + a, 1 + b, 1, 0, a, b, 0, stream, bn);
             if (rc != DIR_OK) return rc;
         }
     return DIR_OK;
+}
+
+extern "C" int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                                 dir_stream_t stream) {
+    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, nullptr, nullptr, stream);
+}
+
+// The data gradients above with the FIRST pass of the BatchNorm backward that consumes them fused into the store loop
+// (dir_bn_bwd_partials is the rest): bn_x = the input of that BatchNorm ([N, H', W', Cout] like the result), stats =
+// [rows][2][Cout] floats, rows = dir_conv_stats_rows(N, Ho, Wo) (x 4 for the stride-2 form: one block of rows per parity
+// class). bn_gamma / bn_beta non-null: the BatchNorm is followed by a ReLU without residual; its mask is recomputed for the sums.
+extern "C" int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* addend, const void* addend_s2,
+                                      const void* relu_mask, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                      int pad, const void* bn_x, const float* bn_gamma, const float* bn_beta,
+                                      const float* bn_mean, const float* bn_rstd, float* stats, dir_stream_t stream) {
+    DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd};
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, 0, stream, &bn);
+}
+
+extern "C" int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                                         const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                         const float* bn_rstd, float* stats, dir_stream_t stream) {
+    DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd};
+    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, &bn, stats, stream);
 }
 
 static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
@@ -641,16 +707,18 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
 // y [N, 2 H, 2 W, Cout]
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                          int cls_a, int cls_b, int variant, dir_stream_t stream) {
+                          int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
-    DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || stats), DIR_EINVAL);
-    DIR_RETURN_IF(addend && (!dir_aligned16(addend) || stats), DIR_EINVAL);     // statistics are of the conv result alone
-    DIR_RETURN_IF(relu_mask && (!dir_aligned16(relu_mask) || stats), DIR_EINVAL);
+    const bool fwd_stats = stats && !bn;                                         // forward statistics are of the conv result alone
+    DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || fwd_stats), DIR_EINVAL);
+    DIR_RETURN_IF(addend && (!dir_aligned16(addend) || fwd_stats), DIR_EINVAL);
+    DIR_RETURN_IF(relu_mask && (!dir_aligned16(relu_mask) || fwd_stats), DIR_EINVAL);
+    DIR_RETURN_IF(bn && (!stats || !bn->x), DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
     const bool cls = cls_a >= 0;
-    DIR_RETURN_IF(cls && (stride != 1 || pad != 0 || addend || addend_s2 || relu_mask || stats), DIR_EINVAL);
+    DIR_RETURN_IF(cls && (stride != 1 || pad != 0 || addend || addend_s2 || relu_mask || fwd_stats), DIR_EINVAL);
     const int Ho = cls ? H : (H + 2 * pad - R) / stride + 1, Wo = cls ? W : (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     DIR_RETURN_IF(addend_s2 && ((Ho | Wo) & 1), DIR_EUNSUPPORTED);
@@ -662,6 +730,9 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     p.addend = static_cast<const uint16_t*>(addend);
     p.mask = static_cast<const uint16_t*>(relu_mask);
     p.addend2 = static_cast<const uint16_t*>(addend_s2);
+    p.bnx = bn ? static_cast<const uint16_t*>(bn->x) : nullptr;
+    p.bn_gamma = bn ? bn->gamma : nullptr; p.bn_beta = bn ? bn->beta : nullptr;
+    p.bn_mean = bn ? bn->mean : nullptr; p.bn_rstd = bn ? bn->rstd : nullptr;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.cpk = Cin / CV_BK; p.KT = R * S * p.cpk;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
@@ -677,11 +748,11 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // pipe bounds the register-staged loop. 1 = register-staged: LDS stages 2 (64 KB, 2 workgroups per CU) for long K loops,
     // 1 (43 KB, 3 per CU, one extra barrier) when the loop is short and the layer is bound by memory latency; prefetch
     // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
-    const int bn = wide ? 128 : 64;
-    const int stage = CV_BM * (bn * 2 + 16) + 4 * 2 * bn * 4;      // epilogue staging + column partials
+    const int tile_n = wide ? 128 : 64;
+    const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
     const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
     if (dma) {
-        const int loop2 = 2 * (CV_BM * CV_ROWB + bn * CV_ROWB);
+        const int loop2 = 2 * (CV_BM * CV_ROWB + tile_n * CV_ROWB);
         const int lds2 = loop2 > stage ? loop2 : stage;
         static bool once_dma = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
                                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
@@ -694,7 +765,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     p.nbuf = p.KT <= 18 ? 1 : 2;
     const int pf = p.KT >= 36 ? 2 : 1;
     if (pf == 2) p.nbuf = 2;                                        // the two-tile prefetch is written for two LDS stages
-    const int loop2 = p.nbuf * (CV_BM * CV_ROWB + bn * CV_ROWB);
+    const int loop2 = p.nbuf * (CV_BM * CV_ROWB + tile_n * CV_ROWB);
     const int lds2 = loop2 > stage ? loop2 : stage;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);

@@ -30,10 +30,24 @@ def _ws(dtype_code, m, c, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+class BwdLink:
+    """Hand-over from a BatchNorm node to the ONE convolution node that consumes its output (``bn_act(fuse_bwd_stats=True)``
+    -> ``conv.conv_bn_input`` / ``conv.projection_pair``): that node's data-gradient kernel produces this BatchNorm's ``dout``,
+    so it also forms the per-channel sums of ``dout`` and ``dout * x`` in its store loop (``dir_conv_dgrad_bnstats``) and
+    leaves them in ``partial``; the BatchNorm backward then runs without its reduction pass (``dir_bn_bwd_partials``).
+    ``needs_relu_claim``: the BatchNorm output went through ``relu(. + residual)``, so the sums are only right when the
+    consumer also applies that ReLU's backward (``defer_relu_grad`` claimed)."""
+    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "recompute_mask", "needs_relu_claim", "partial")
+
+    def __init__(self):
+        self.x = self.gamma = self.beta = self.mean = self.rstd = self.partial = None
+        self.recompute_mask = self.needs_relu_claim = False
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training, partial,
-                deferred=None):
+                deferred=None, link=None):
         if not x.is_cuda:
             raise L.DirHipError(f"bn_act: input on {x.device}; the fused BatchNorm runs only as HIP kernels (no CPU fallback)")
         x = _nhwc(x)
@@ -67,6 +81,11 @@ class _BNActFn(torch.autograd.Function):
             ctx.relu = bool(relu)
             ctx.has_res = residual is not None
             ctx.deferred = deferred
+            ctx.link = link
+            if link is not None:
+                link.x, link.gamma, link.beta, link.mean, link.rstd = x, gamma, beta, mean, rstd
+                link.recompute_mask = bool(relu) and residual is None
+                link.needs_relu_claim = bool(relu) and residual is not None
         else:
             L.check(L.lib().dir_bn_fwd_eval(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(gamma), L.ptr(beta),
                                             L.ptr(running_mean), L.ptr(running_var), float(eps), int(relu), L.ptr(ws),
@@ -97,12 +116,21 @@ class _BNActFn(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         ws = _ws(code, m, c, x.device)
-        L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
-                                   L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(relu),
-                                   L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
+        link = getattr(ctx, "link", None)
+        part = None if link is None else link.partial
+        if part is not None and dres is None and y is None:
+            # the consumer's data-gradient kernel already summed dout and dout * x per channel (BwdLink): finalize + apply only
+            link.partial = None
+            L.check(L.lib().dir_bn_bwd_partials(L.ptr(dout), L.ptr(x), L.ptr(dx), code, m, c, L.ptr(gamma), L.ptr(beta), L.ptr(mean),
+                                                L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(relu), L.ptr(part), part.shape[0],
+                                                L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd_partials")
+        else:
+            L.check(L.lib().dir_bn_bwd(L.ptr(dout), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), code, m, c, L.ptr(gamma),
+                                       L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), int(relu),
+                                       L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
         if dres is None and ctx.has_res:
             dres = dout
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class _BNJoinFn(torch.autograd.Function):
@@ -196,12 +224,15 @@ def bn_join(x, bn, partial, r, bn_r, partial_r, relu=True, defer_relu_grad=False
     return y
 
 
-def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False):
+def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False, fuse_bwd_stats=False):
     """``relu(bn(x) + residual)`` for a channels_last tensor with ``bn`` an ``nn.BatchNorm2d``. ``partial`` =
     the ``[rows][2][C]`` statistics partials emitted by ``conv.conv_bn_input`` for this very ``x`` (training only).
     ``defer_relu_grad``: the result carries a flag (``._dir_relu_flag``) that the ONE consumer of the result may claim
     (``conv.conv_bn_input(..., relu_flag=)``), promising to deliver the gradient with this node's ReLU backward already
-    applied; the backward here then skips the mask (and the read of the saved output, and the shortcut-gradient write)."""
+    applied; the backward here then skips the mask (and the read of the saved output, and the shortcut-gradient write).
+    ``fuse_bwd_stats``: the caller guarantees that the result has exactly ONE consumer and that it is a convolution node of
+    ``conv.py``; the result then carries a ``BwdLink`` (``._dir_bn_link``) through which that node's data-gradient kernel
+    delivers this BatchNorm's backward reduction (bf16 training only)."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         counter = getattr(bn, "_dir_step_counter", None)
@@ -214,10 +245,16 @@ def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     deferred = [False] if (defer_relu_grad and relu and training and torch.is_grad_enabled()) else None
+    link = None
+    if fuse_bwd_stats and training and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and x.is_cuda \
+            and (residual is None or (relu and deferred is not None)):
+        link = BwdLink()
     y = _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
-                       partial if training else None, deferred)
+                       partial if training else None, deferred, link)
     if deferred is not None:
         y._dir_relu_flag = deferred
+    if link is not None:
+        y._dir_bn_link = link
     return y
 
 

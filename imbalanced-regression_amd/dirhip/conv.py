@@ -27,7 +27,13 @@ def supported(cin, cout, x=None):
     return True
 
 
-def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None):
+def _bn_link_args(link):
+    g = link.recompute_mask
+    return (L.ptr(link.x), L.ptr(link.gamma) if g else None, L.ptr(link.beta) if g else None, L.ptr(link.mean) if g else None,
+            L.ptr(link.rstd) if g else None)
+
+
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None, bn_link=None):
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -58,6 +64,18 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         assert addend_s2.shape == (n, cout, ho // 2, wo // 2) and addend_s2.dtype == torch.bfloat16 and not want_stats and stride == 1
         if not addend_s2.is_contiguous(memory_format=torch.channels_last):
             addend_s2 = addend_s2.contiguous(memory_format=torch.channels_last)
+    if bn_link is not None:
+        # data gradient whose result is the `dout` of the BatchNorm behind bn_link: that node's backward reduction is formed in
+        # the store loop (bn.BwdLink)
+        assert stride == 1 and not want_stats and bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
+        rows = L.lib().dir_conv_stats_rows(n, ho, wo)
+        part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+        L.check(L.lib().dir_conv_dgrad_bnstats(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
+                                               cin, cout, r, s, padding, *_bn_link_args(bn_link), L.ptr(part),
+                                               L.stream_ptr(x.device)), "dir_conv_dgrad_bnstats")
+        bn_link.partial = part
+        return y
+    if addend_s2 is not None:
         L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
                                             cin, cout, r, s, padding, L.stream_ptr(x.device)), "dir_conv_dgrad_join")
         return y
@@ -94,9 +112,10 @@ class _ConvFn(torch.autograd.Function):
     (odd-sized maps) use the general float32 data gradient of ``conv_f32`` — never a library kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input):
+    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input, bn_link=None):
         ctx.stride, ctx.padding = stride, padding
         ctx.alias_input = alias_input
+        ctx.bn_link = bn_link                    # bn.BwdLink of the BatchNorm that produced x (its backward reduction is ours)
         # relu_input: x is the output of a relu(bn(.) + shortcut) node that was promised its gradient with the ReLU
         # backward already applied (bn.bn_act(defer_relu_grad=True)): the data gradient is masked with x > 0 on store
         ctx.relu_input = relu_input
@@ -120,7 +139,8 @@ class _ConvFn(torch.autograd.Function):
         x, w16, w16_rot = ctx.saved_tensors
         if dy is None:                                                           # only the alias output was used
             assert not ctx.relu_input
-            return dalias, None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None, None
+        link = ctx.bn_link
         if dalias is not None and dalias.dtype != torch.bfloat16:
             dalias = dalias.to(torch.bfloat16)
         if dy.dtype != torch.bfloat16:
@@ -132,7 +152,7 @@ class _ConvFn(torch.autograd.Function):
             # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
             # in/out-transposed weights and padding R-1-pad
             dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias,
-                              relu_mask=x if ctx.relu_input else None)
+                              relu_mask=x if ctx.relu_input else None, bn_link=link)
             dalias = None
             need_dx = False
         dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
@@ -140,8 +160,15 @@ class _ConvFn(torch.autograd.Function):
             # 3x3 / stride 2 / pad 1: four stride-1 launches, one per output-pixel parity class (dir_conv_dgrad_s2)
             n_, cin_, h_, w_ = x.shape
             dx = torch.empty((n_, cin_, h_, w_), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-            L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
-                                              L.stream_ptr(x.device)), "dir_conv_dgrad_s2")
+            if link is not None and dalias is None:
+                part = torch.empty((4 * L.lib().dir_conv_stats_rows(n_, h_ // 2, w_ // 2), 2, cin_), dtype=torch.float32, device=x.device)
+                L.check(L.lib().dir_conv_dgrad_s2_bnstats(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
+                                                          *_bn_link_args(link), L.ptr(part), L.stream_ptr(x.device)),
+                        "dir_conv_dgrad_s2_bnstats")
+                link.partial = part
+            else:
+                L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
+                                                  L.stream_ptr(x.device)), "dir_conv_dgrad_s2")
             need_dx = False
         if need_dx:
             # strided data gradients the bf16 kernels do not take (odd-sized maps, a stride-2 1x1 outside a projection
@@ -151,7 +178,9 @@ class _ConvFn(torch.autograd.Function):
                                   ctx.stride, ctx.padding).to(torch.bfloat16)
         if dalias is not None:                                                   # strided layer: eager accumulation
             dx = dalias if dx is None else dx + dalias
-        return dx, dw, None, None, None, None, None, None, None
+            if link is not None:
+                link.partial = None                                              # the sums were of an incomplete gradient
+        return dx, dw, None, None, None, None, None, None, None, None
 
 
 class _ProjectionPairFn(torch.autograd.Function):
@@ -162,9 +191,10 @@ class _ProjectionPairFn(torch.autograd.Function):
     of the previous block's output. No strided transposed convolution, no zero fill, no gradient-add kernel."""
 
     @staticmethod
-    def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input):
+    def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input, bn_link=None):
         ctx.set_materialize_grads(False)
         ctx.stride_d, ctx.relu_input = stride_d, relu_input
+        ctx.bn_link = bn_link
         if want_stats:
             y1, s1 = conv2d_igemm(x, w1_16, 1, 0, want_stats=True)
             yd, sd = conv2d_igemm(x, wd_16, stride_d, 0, want_stats=True)
@@ -190,15 +220,16 @@ class _ProjectionPairFn(torch.autograd.Function):
         compact = conv2d_igemm(dyd, wd_rot, 1, 0) if dyd is not None else None
         if dy1 is None:
             raise L.DirHipError("projection pair: conv1's output received no gradient")
+        link = ctx.bn_link
         if compact is None:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, relu_mask=mask)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, relu_mask=mask, bn_link=link)
         elif ctx.stride_d == 1:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask, bn_link=link)
         else:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask, bn_link=link)
         dw1 = conv2d_wgrad(dy1, x, 1, 1, 0)
         dwd = conv2d_wgrad(dyd, x, 1, ctx.stride_d, 0) if dyd is not None else None
-        return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None
+        return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -329,8 +360,14 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     relu_input = bool(relu_flag is not None and aliasing and w16_rot is not None and conv.stride[0] == 1 and not relu_flag[0])
     if relu_input:
         relu_flag[0] = True
+    # BatchNorm that produced x and asked for its backward reduction (bn.BwdLink): ours when this node's data gradient is the
+    # whole gradient of x (sole consumer; behind a relu(. + residual) only together with that ReLU's backward)
+    link = getattr(x, "_dir_bn_link", None)
+    if link is not None and not (grad_mode and x.requires_grad and w16_rot is not None and link.x is not None
+                                 and (relu_input if link.needs_relu_claim else not alias_input)):
+        link = None
     y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if grad_mode else None, conv.stride[0], conv.padding[0],
-                                    want_stats, aliasing, relu_input)
+                                    want_stats, aliasing, relu_input, link)
     if alias_input:
         return y, stats, (alias if alias is not None else x)
     return y, stats
@@ -357,8 +394,12 @@ def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
     relu_input = bool(relu_flag is not None and grad_mode and x.requires_grad and not relu_flag[0])
     if relu_input:
         relu_flag[0] = True
+    link = getattr(x, "_dir_bn_link", None)
+    if link is not None and not (grad_mode and x.requires_grad and link.x is not None
+                                 and (relu_input or not link.needs_relu_claim)):
+        link = None
     return _ProjectionPairFn.apply(x, conv1.weight, w1_16, w1_rot, conv_d.weight, wd_16, wd_rot, conv_d.stride[0], want_stats,
-                                   relu_input)
+                                   relu_input, link)
 
 
 def projection_pair_ok(conv1, conv_d, x=None):

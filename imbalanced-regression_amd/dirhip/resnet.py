@@ -45,6 +45,18 @@ def set_graph_fusion(enabled):
     return prev
 
 
+# BatchNorm backward: form the per-channel sums inside the data-gradient kernel that produces the BatchNorm's `dout`
+# (bn.BwdLink) instead of in a reduction pass of their own. Off = the plain three-pass dir_bn_bwd (tests compare the two).
+_FUSE_BN_BWD = [True]
+
+
+def set_bn_bwd_fusion(enabled):
+    """Returns the previous setting."""
+    prev = _FUSE_BN_BWD[0]
+    _FUSE_BN_BWD[0] = bool(enabled)
+    return prev
+
+
 def _fusable(x):
     return _FUSED_GRAPH[0] and x.dtype in (torch.bfloat16, torch.float32)
 
@@ -56,14 +68,15 @@ def _own_conv(x, conv):
     return x.dtype == torch.bfloat16 and _igemm_ok(conv.in_channels, conv.out_channels, x)
 
 
-def _conv_bn(x, conv, bn, relu, residual=None, defer_relu_grad=False):
+def _conv_bn(x, conv, bn, relu, residual=None, defer_relu_grad=False, fuse_bwd_stats=False):
     """conv -> BatchNorm (+ residual) (+ ReLU). bf16 activations: hand-written MFMA implicit-GEMM convolution whose
     epilogue already produced the BatchNorm statistics, then ONE fused normalise/add/ReLU pass. float32 activations
     (parity mode): the exact-float32 MFMA convolution + the same fused BatchNorm node. bf16 layers whose channel counts
     the MFMA kernel does not take are computed by the float32 kernels (casts around them)."""
     if _own_conv(x, conv):
         y, partial = conv_bn_input(x, conv, want_stats=bn.training)
-        return bn_act(y, bn, relu=relu, residual=residual, partial=partial, defer_relu_grad=defer_relu_grad)
+        return bn_act(y, bn, relu=relu, residual=residual, partial=partial, defer_relu_grad=defer_relu_grad,
+                      fuse_bwd_stats=fuse_bwd_stats)
     return bn_act(conv_f32(x, conv), bn, relu=relu, residual=residual)
 
 
@@ -94,8 +107,9 @@ class Bottleneck(nn.Module):
             # relu(bn3(conv3(.)) + bn_d(conv_d(x))) is one join with both normalisations in ONE apply pass
             y, partial, r, partial_r = projection_pair(x, self.conv1, self.downsample[0], want_stats=True,
                                                        relu_flag=getattr(x, "_dir_relu_flag", None))
-            y = bn_act(y, self.bn1, relu=True, partial=partial)
-            y = _conv_bn(y, self.conv2, self.bn2, relu=True)
+            # (bn1 / bn2 outputs have one consumer, the next convolution: its data-gradient kernel also forms their backward sums)
+            y = bn_act(y, self.bn1, relu=True, partial=partial, fuse_bwd_stats=_FUSE_BN_BWD[0])
+            y = _conv_bn(y, self.conv2, self.bn2, relu=True, fuse_bwd_stats=_FUSE_BN_BWD[0])
             y3, partial3 = conv_bn_input(y, self.conv3, want_stats=True)
             return bn_join(y3, self.bn3, partial3, r, self.downsample[1], partial_r, relu=True, defer_relu_grad=True)
         if fused and _own_conv(x, self.conv1) and _igemm_ok(self.conv1.in_channels, self.conv1.out_channels, x):
@@ -105,14 +119,17 @@ class Bottleneck(nn.Module):
             # (and, when x is the previous block's relu(bn3 + shortcut), that node's ReLU backward is applied there too)
             y, partial, xin = conv_bn_input(x, self.conv1, want_stats=self.bn1.training, alias_input=True,
                                             relu_flag=getattr(x, "_dir_relu_flag", None))
-            y = bn_act(y, self.bn1, relu=True, partial=partial)
+            y = bn_act(y, self.bn1, relu=True, partial=partial, fuse_bwd_stats=_FUSE_BN_BWD[0])
             shortcut = xin if self.downsample is None else _conv_bn(xin, self.downsample[0], self.downsample[1], relu=False)
         else:
             shortcut = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-            y = _conv_bn(x, self.conv1, self.bn1, relu=True)
-        y = _conv_bn(y, self.conv2, self.bn2, relu=True)
-        # relu(bn3(conv3(.)) + shortcut); the next block's conv1 may take over the ReLU backward of this node
-        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut, defer_relu_grad=fused)
+            y = _conv_bn(x, self.conv1, self.bn1, relu=True, fuse_bwd_stats=fused and _FUSE_BN_BWD[0])
+        y = _conv_bn(y, self.conv2, self.bn2, relu=True, fuse_bwd_stats=fused and _FUSE_BN_BWD[0])
+        # relu(bn3(conv3(.)) + shortcut); the next block's conv1 may take over the ReLU backward of this node — and with it
+        # the reduction pass of bn3's backward (the block output is read by that conv1 node alone: identity shortcuts go through
+        # its alias output)
+        return _conv_bn(y, self.conv3, self.bn3, relu=True, residual=shortcut, defer_relu_grad=fused,
+                        fuse_bwd_stats=fused and _FUSE_BN_BWD[0])
 
 
 class ResNet(nn.Module):

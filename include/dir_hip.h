@@ -217,6 +217,14 @@ int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void*
                int64_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                const float* save_rstd, float* dgamma, float* dbeta, int relu, void* workspace,
                size_t workspace_bytes, dir_stream_t stream);
+/* dir_bn_bwd minus its first pass: the per-channel sums of g and g*x arrive as `partial` [partial_rows][2][C] f32 from the
+ * data-gradient kernel that produced dout (dir_conv_dgrad_bnstats / dir_conv_dgrad_s2_bnstats), so dout and x are read once
+ * (apply pass) instead of twice.  relu != 0: ReLU layer without residual, mask recomputed from x (as dir_bn_bwd with
+ * out == NULL).  Replaces the BatchNorm2d backward of imdb-wiki-dir/resnet.py:45-50 (bn1/bn2/bn3 of a Bottleneck). */
+int dir_bn_bwd_partials(const void* dout, const void* x, void* dx, int dtype, int64_t M, int C, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                        int relu, const float* partial, int partial_rows, void* workspace, size_t workspace_bytes,
+                        dir_stream_t stream);
 /* The two halves of dir_bn_fwd_train[_partials] on their own, for the projection-shortcut join
  * relu(bn3(x) + bn_d(r)) of imdb-wiki-dir/resnet.py:63-68 (bn_d = downsample[1]): both BatchNorms are prepared
  * (statistics -> save_mean/save_rstd, running statistics, coef[2][C] = scale/shift), then ONE apply pass normalises
@@ -281,6 +289,20 @@ int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const v
  * scatter a strided transposed convolution would write (and this launch re-read) never exists.  Ho, Wo even. */
 int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
                         void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, dir_stream_t stream);
+/* dir_conv_dgrad_join / dir_conv_dgrad_s2 with the FIRST pass of the BatchNorm backward that consumes the result fused into
+ * the store loop: the result y is the gradient of the OUTPUT of a BatchNorm (bn1 / bn2 / bn3 of a Bottleneck, resnet.py:45-50)
+ * whose input is bn_x ([N, Ho, Wo, Cout] bf16, the geometry of y); stats [rows][2][Cout] f32 receives, per 128-row tile, the
+ * sums of g and g * bn_x over the rows (g = y as stored, in bf16) — the `partial` operand of dir_bn_bwd_partials.
+ * rows = dir_conv_stats_rows(N, Ho, Wo), x 4 for the stride-2 form (one block of rows per parity class).
+ * bn_gamma / bn_beta / bn_mean / bn_rstd non-NULL: the BatchNorm is followed by a ReLU (no residual); g is taken under that
+ * ReLU's mask, recomputed as bn_x * a + b > 0 with the forward's coefficients (the stored y stays unmasked). */
+int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
+                           void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, const void* bn_x,
+                           const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_rstd,
+                           float* stats, dir_stream_t stream);
+int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                              const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                              const float* bn_rstd, float* stats, dir_stream_t stream);
 /* Stem convolution 7x7 / stride 2 / pad 3, 3 -> 64 channels (imdb-wiki-dir/resnet.py:79,129), MFMA without an im2col
  * buffer.  x [N, H, W, 3] bf16 (channels_last image), wpack = dir_stem_conv_prep_weights(w) with w the float32 master
  * weight [64][7][7][3] (= channels_last [64, 3, 7, 7]); y [N, Ho, Wo, 64] bf16; stats (may be NULL)
