@@ -326,6 +326,14 @@ void wg_launch(const WgP& p, int nblocks, hipStream_t s) {
 
 }  // namespace
 
+// (also used by dir_conv_wgrad3.hip) dw[i] = sum over splits, in split order, of part[split][i]; n % 4 == 0
+extern "C" int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float* dw, dir_stream_t stream) {
+    DIR_RETURN_IF(!part || !dw || splits <= 0 || n == 0 || (n & 3), DIR_EINVAL);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(dir_cdiv((long long)n / 4, RD_COLS)), dim3(DIR_TPB), 0, dir_s(stream), part, splits, n, dw);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
 extern "C" size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;

@@ -84,6 +84,18 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
     return (y, stats) if want_stats else y
 
 
+# 3x3 / stride-1 weight gradients: all nine taps in one pass over dY and X (dir_conv_wgrad3x3). Off = the per-tap kernel
+# (tests and tools compare the two).
+_WGRAD3_ALL_TAPS = [True]
+
+
+def set_wgrad3_all_taps(enabled):
+    """Returns the previous setting."""
+    prev = _WGRAD3_ALL_TAPS[0]
+    _WGRAD3_ALL_TAPS[0] = bool(enabled)
+    return prev
+
+
 def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
     """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
@@ -94,11 +106,18 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     r = s = kernel_size
+    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if kernel_size == 3 and stride == 1 and padding == 1 and _WGRAD3_ALL_TAPS[0]:
+        nbytes = L.lib().dir_conv_wgrad3x3_workspace(n, h, w, cin, cout)
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            L.check(L.lib().dir_conv_wgrad3x3(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
+                                              L.stream_ptr(x.device)), "dir_conv_wgrad3x3")
+            return dw
     nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding)
     if nbytes == 0:
         raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout}")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, L.ptr(ws),
                                    ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
     return dw

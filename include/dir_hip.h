@@ -333,6 +333,21 @@ size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, i
 int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
                    int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
                    dir_stream_t stream);
+/* The 3x3 / stride-1 / pad-1 weight gradients (conv2 of every Bottleneck but the three strided ones, resnet.py:46-47) in ONE
+ * pass over dY and X for all nine taps: H == W in {56, 28, 14, 7}, Cin % 64 == 0, Cout % 64 == 0 (workspace 0 = not this
+ * shape; dir_conv_wgrad then runs its per-tap form).  A workgroup keeps a 64 x 64 (co x ci) block of all nine taps in
+ * registers and walks over chunks of whole image rows staged in LDS in their natural layout (LDS-DMA); the taps are row
+ * offsets of the transposing LDS reads (ds_read_b64_tr_b16).  Same deterministic split-K reduction as dir_conv_wgrad. */
+size_t dir_conv_wgrad3x3_workspace(int N, int H, int W, int Cin, int Cout);
+int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout, void* workspace,
+                      size_t workspace_bytes, dir_stream_t stream);
+/* dw[i] = sum over s < splits, in order, of part[s * n + i] (the reduction pass of both weight-gradient forms); n % 4 == 0. */
+int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float* dw, dir_stream_t stream);
+/* Test probe of the hardware-transposing LDS read the 3x3 weight gradient is built on: LDS holds the uint16 ramp 0, 1, 2, ...
+ * (8192 elements); lane l of ONE wavefront issues ds_read_b64_tr_b16 at byte address addr_bytes[l] (8-byte aligned) and
+ * out[4 l .. 4 l + 3] receives its four 16-bit results. */
+int dir_probe_tr16(const int* addr_bytes, void* out, dir_stream_t stream);
+
 
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC bf16 (resnet.py:82,131 nn.MaxPool2d) with one argmax byte (0..8 = r*3+s,
  * first maximum in scan order like torch) per output element; backward is a gather over the <= 2x2 windows that
