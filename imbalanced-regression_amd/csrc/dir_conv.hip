@@ -93,6 +93,11 @@ __device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsign
 
 // Epilogue shared by the K-loop variants: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free: the caller
 // has passed a barrier after its last fragment read) -> 16-B row stores with the fused statistics / addend / mask options.
+// Every global operand of the store loop (shortcut gradient, compact stride-2 gradient, ReLU mask, BatchNorm input for the fused
+// backward sums) is fetched for all of the thread's rows BEFORE the barrier that publishes the staging tile — up to 8 rows x 4
+// streams x 16 B in flight per lane while the tile is staged. Written as load-then-use inside the loop, each of them costs a
+// full memory round trip (the compiler keeps `s_waitcnt vmcnt(0)` right behind every load: found in the ISA), 8 x 3 serial
+// round trips per workgroup in the data-gradient launches.
 template <int BN>
 __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[(BN == 128) ? 2 : 1][2], unsigned char* smem, int t, int m0,
                                             int n0, int mt) {
@@ -107,20 +112,17 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 34 KB)
     float* Ss = reinterpret_cast<float*>(smem + CV_BM * CS_STRIDE);   // [4 waves][2][BN] column partials (<= 4 KB)
     cv_stage_acc<MI, NI, CS_STRIDE>(acc, Cs + (wm * WM + frow) * CS_STRIDE + (wn * 64 + 4 * fhalf) * 2);
-    __syncthreads();
     constexpr int CPR = BN / 8;                                 // 16-B chunks per C row
     constexpr int RPI = DIR_TPB / CPR;                          // rows per pass of the workgroup
+    constexpr int NIT = CV_BM / RPI;                            // passes = rows per thread (8 or 4)
     const int srow = t / CPR, sch = t - srow * CPR;
     const unsigned char* cs = Cs + srow * CS_STRIDE + sch * 16;
-    size_t go = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
+    const size_t go0 = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
     const size_t gstep = (size_t)RPI * p.Cout;
     const bool full = m0 + CV_BM <= p.M;
-    // BatchNorm statistics of the ROUNDED outputs (what the following BatchNorm reads): this thread's 8 channels over the rows
-    // it stores, then over the lanes / wavefronts that share the channel chunk, in a fixed order
-    float ssum[8], ssq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
     const bool fwd_stats = p.stats && !p.bnx;
+    const bool decode = p.o2 || p.addend2;                      // rows need their (n, ho, wo)
+
     // fused BatchNorm-backward partials: (sum g, sum g * bnx) of the gradient as stored, optionally under the recomputed ReLU mask
     float maf[8], mbf[8];
     if (p.bnx && p.bn_gamma) {
@@ -132,64 +134,68 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
             mbf[j] = (float)((double)p.bn_beta[ch] - (double)p.bn_mean[ch] * gm * rs);
         }
     }
-#define CV_BN_ACC(cvec, xptr)                                                                                   \
-    {                                                                                                           \
-        const uint4 xv = *reinterpret_cast<const uint4*>(xptr);                                                 \
-        const uint32_t gw[4] = {(cvec).x, (cvec).y, (cvec).z, (cvec).w};                                        \
-        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};                                                        \
-        _Pragma("unroll")                                                                                       \
-        for (int q2 = 0; q2 < 4; ++q2) {                                                                        \
-            float g0 = __uint_as_float(gw[q2] << 16), g1 = __uint_as_float(gw[q2] & 0xffff0000u);              \
-            const float x0 = __uint_as_float(xw[q2] << 16), x1 = __uint_as_float(xw[q2] & 0xffff0000u);        \
-            if (p.bn_gamma) {                                                                                   \
-                if (!(x0 * maf[2 * q2] + mbf[2 * q2] > 0.0f)) g0 = 0.0f;                                        \
-                if (!(x1 * maf[2 * q2 + 1] + mbf[2 * q2 + 1] > 0.0f)) g1 = 0.0f;                                \
-            }                                                                                                   \
-            ssum[2 * q2] += g0; ssq[2 * q2] += g0 * x0; ssum[2 * q2 + 1] += g1; ssq[2 * q2 + 1] += g1 * x1;     \
-        }                                                                                                       \
-    }
+    // BatchNorm statistics of the ROUNDED outputs (what the following BatchNorm reads): this thread's 8 channels over the rows
+    // it stores, then over the lanes / wavefronts that share the channel chunk, in a fixed order
+    float ssum[8], ssq[8];
 #pragma unroll
-    for (int i = 0; i < CV_BM / RPI; ++i, go += gstep) {
-        if (full || m0 + srow + i * RPI < p.M) {
-            uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
-            if (fwd_stats) {
-                const uint32_t sw[4] = {c.x, c.y, c.z, c.w};
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+
+    // The thread's rows in two halves: (operand loads of a half, all in flight together) -> (its arithmetic and stores). The first
+    // half's loads are issued before the barrier that publishes the staging tile. (All rows at once would need 100+ registers.)
+    constexpr int HALF = NIT / 2;
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    const float f0 = __uint_as_float(sw[q2] << 16), f1 = __uint_as_float(sw[q2] & 0xffff0000u);
-                    ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
+    for (int hh = 0; hh < 2; ++hh) {
+        uint32_t orow[HALF];                                    // element offset of the row's chunk in y (and in bnx / addend / mask)
+        uint32_t o2row[HALF];                                   // ... of its compact stride-2 addend, or ~0u
+        uint4 v_add[HALF], v_mask[HALF], v_bnx[HALF];
+#pragma unroll
+        for (int ii = 0; ii < HALF; ++ii) {
+            const int i = hh * HALF + ii;
+            orow[ii] = (uint32_t)(go0 + (size_t)i * gstep);
+            o2row[ii] = ~0u;
+            v_add[ii] = v_mask[ii] = v_bnx[ii] = make_uint4(0u, 0u, 0u, 0u);
+            if (full || m0 + srow + i * RPI < p.M) {
+                if (decode) {
+                    const int m = m0 + srow + i * RPI;
+                    int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+                    if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                    int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+                    if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+                    if (p.o2)                                    // parity class of a stride-2 data gradient: scattered rows
+                        orow[ii] = (uint32_t)((((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b) * p.Cout + n0 + sch * 8);
+                    if (p.addend2 && !((ho | wo) & 1))           // rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :]
+                        o2row[ii] = (uint32_t)(((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8);
                 }
+                if (p.addend) v_add[ii] = *reinterpret_cast<const uint4*>(p.addend + orow[ii]);
+                if (p.mask) v_mask[ii] = *reinterpret_cast<const uint4*>(p.mask + orow[ii]);
+                if (p.bnx) v_bnx[ii] = *reinterpret_cast<const uint4*>(p.bnx + orow[ii]);
             }
-            if (p.o2) {                                         // parity class of a stride-2 data gradient: scattered rows
-                const int m = m0 + srow + i * RPI;
-                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
-                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
-                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-                const size_t orow = ((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b;
-                *reinterpret_cast<uint4*>(p.y + orow * p.Cout + n0 + sch * 8) = c;
-                if (p.bnx) CV_BN_ACC(c, p.bnx + orow * p.Cout + n0 + sch * 8);
-                continue;
-            }
-            if (p.addend) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
-                const uint4 a = *reinterpret_cast<const uint4*>(p.addend + go);
-                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+        }
+        if (hh == 0) __syncthreads();
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2)
-                    cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
-                                          __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
-                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
-            if (p.addend2) {                                    // rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :]
-                const int m = m0 + srow + i * RPI;
-                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
-                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
-                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
-                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
-                if (!((ho | wo) & 1)) {
-                    const size_t co = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8;
-                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend2 + co);
+        for (int ii = 0; ii < HALF; ++ii) {
+            const int i = hh * HALF + ii;
+            if (full || m0 + srow + i * RPI < p.M) {
+                uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+                if (fwd_stats) {
+                    const uint32_t sw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const float f0 = __uint_as_float(sw[q2] << 16), f1 = __uint_as_float(sw[q2] & 0xffff0000u);
+                        ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
+                    }
+                }
+                if (p.addend) {                                 // y = bf16(bf16(conv) + addend), like an eager add kernel
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                    const uint32_t aw[4] = {v_add[ii].x, v_add[ii].y, v_add[ii].z, v_add[ii].w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2)
+                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+                if (p.addend2 && o2row[ii] != ~0u) {            // (three launches per step: loaded here, not ahead)
+                    const uint4 a = *reinterpret_cast<const uint4*>(p.addend2 + o2row[ii]);
                     uint32_t cw[4] = {c.x, c.y, c.z, c.w};
                     const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -198,23 +204,34 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                                               __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
                     c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
                 }
-            }
-            if (p.mask) {                                       // ReLU backward of the tensor this gradient belongs to
-                const uint4 k = *reinterpret_cast<const uint4*>(p.mask + go);
-                const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
-                uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+                if (p.mask) {                                   // ReLU backward of the tensor this gradient belongs to
+                    const uint32_t kw[4] = {v_mask[ii].x, v_mask[ii].y, v_mask[ii].z, v_mask[ii].w};
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
-                    if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
+                        if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                    }
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
                 }
-                c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                *reinterpret_cast<uint4*>(p.y + orow[ii]) = c;
+                if (p.bnx) {
+                    const uint32_t gw[4] = {c.x, c.y, c.z, c.w};
+                    const uint32_t xw[4] = {v_bnx[ii].x, v_bnx[ii].y, v_bnx[ii].z, v_bnx[ii].w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        float g0 = __uint_as_float(gw[q2] << 16), g1 = __uint_as_float(gw[q2] & 0xffff0000u);
+                        const float x0 = __uint_as_float(xw[q2] << 16), x1 = __uint_as_float(xw[q2] & 0xffff0000u);
+                        if (p.bn_gamma) {
+                            if (!(x0 * maf[2 * q2] + mbf[2 * q2] > 0.0f)) g0 = 0.0f;
+                            if (!(x1 * maf[2 * q2 + 1] + mbf[2 * q2 + 1] > 0.0f)) g1 = 0.0f;
+                        }
+                        ssum[2 * q2] += g0; ssq[2 * q2] += g0 * x0; ssum[2 * q2 + 1] += g1; ssq[2 * q2 + 1] += g1 * x1;
+                    }
+                }
             }
-            *reinterpret_cast<uint4*>(p.y + go) = c;
-            if (p.bnx) CV_BN_ACC(c, p.bnx + go);
         }
     }
-#undef CV_BN_ACC
     if (p.stats) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -607,11 +624,226 @@ conv_igemm_dma_kernel(ConvP p) {
     cv_epilogue<BN>(p, acc, smem, t, m0, n0, mt);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 on 56^2, 28^2, 14^2 maps (conv2 of the Bottlenecks and, with rotated weights, its data gradient):
+// the K loops above fetch the A tile once per filter tap — nine shifted copies of the same pixels — and their time is that
+// L2 -> LDS traffic (~12 TB/s chip-wide), not the MFMAs. Here the M tile is a chunk of RB whole image rows (<= 112 pixels of
+// the 128-row MFMA tile; the padded rows are computed on garbage-free dummy pixels and never stored) and, per 64-channel
+// block, its input PATCH ((RB + 2) rows x P pixels, zero border materialised, P = row pitch rounded up to a multiple of 16) is
+// DMA'd into LDS ONCE; the nine taps then read their A fragments from the patch at a row offset of (r * P + s) * 128 bytes,
+// and only the 64-wide weight slices stream per tap. A traffic / 9: total L2 -> LDS bytes x0.48 (64 channels) ... x0.74 (256).
+// LDS image of the patch: 128-byte pixel rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7 like the A tile above (applied
+// on the DMA source side); r * P is a multiple of 16 rows, so the tap row is an instruction immediate and only the three tap
+// columns need their own addresses. The DMA is inline assembly (see dir_conv_wgrad3.hip: the compiler would otherwise drain
+// the pending LDS-DMA in front of LDS reads it cannot disambiguate) with an explicit s_waitcnt before each barrier.
+template <int WI> struct CpGeom {
+    static constexpr int RB = (WI == 56) ? 2 : (WI == 28) ? 4 : 7;
+    static constexpr int CPI = WI / RB;
+    static constexpr int P = (WI == 56) ? 64 : (WI == 28) ? 32 : 16;
+    static constexpr int KPIX = RB * WI;
+    static constexpr int PROWS = (RB + 2) * P;                    // patch rows (a multiple of 8)
+    static constexpr int PPIECES = PROWS / 8;
+    static constexpr int PPW = (PPIECES + 3) / 4;                 // patch pieces per wavefront
+    static constexpr int PATCH = PROWS * CV_ROWB;
+    static_assert(WI % RB == 0 && P % 16 == 0 && P >= WI + 2 && PROWS % 8 == 0, "chunk geometry");
+};
+
+typedef __attribute__((ext_vector_type(4))) uint32_t cp_u32x4;
+__device__ __forceinline__ cp_u32x4 cp_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    cp_u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void cp_dma16(cp_u32x4 rs, uint32_t lds_addr, int voffset, int soffset) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ void cp_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int WI, int BN>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(2)))
+conv3x3_patch_kernel(ConvP p) {
+    using G = CpGeom<WI>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int B_BYTES = BN * CV_ROWB;
+    constexpr int BI = BN / 32;                           // B pieces per wavefront and K-step
+    constexpr int MI = (BN == 128) ? 2 : 1;
+    constexpr int NI = 2;
+    constexpr int WM = MI * 32;
+    // LDS: [patch stage 0][patch stage 1 (only used when Cin > 64)][B stage 0][B stage 1]
+    const int npatch = p.cpk > 1 ? 2 : 1;
+    const uint32_t b_base = (uint32_t)(npatch * G::PATCH);
+    int lin;
+    {
+        const int b = blockIdx.x, q = p.nblocks / 8, r = p.nblocks % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int mt = lin / p.ntn, nt = lin - mt * p.ntn;    // mt = chunk index
+    const int n_img = mt / G::CPI, h0 = (mt - n_img * G::CPI) * G::RB;
+    const int m0 = (n_img * WI + h0) * WI, n0 = nt * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    typedef __attribute__((address_space(3))) unsigned char* cp_lds_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(cp_lds_t)smem;
+
+    const cp_u32x4 rs_x = cp_rsrc(p.x, (uint32_t)(p.N * p.H * p.W) * (uint32_t)p.Cin * 2u);
+    const int K = p.KT * CV_BK;
+    const cp_u32x4 rs_w = cp_rsrc(p.w, (uint32_t)p.Cout * (uint32_t)K * 2u);
+
+    // ---- patch DMA roles: piece q = wave + 4 i = patch rows 8 q .. 8 q + 7; the lane fills physical chunk (lane & 7) of row
+    // 8 q + (lane >> 3) with LOGICAL chunk (lane & 7) ^ ((row >> 1) & 7)
+    const int lr = lane >> 3, lc = lane & 7;
+    int prel[G::PPW];                                     // byte offset of the lane's source chunk relative to pixel (h0 - 1, -1) of
+                                                          // the image, channel block 0; CV_OOB = zero border / unused slot
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) {
+        const int q = wave + 4 * i;
+        prel[i] = CV_OOB;
+        if (q < G::PPIECES) {
+            const int row = q * 8 + lr;
+            const int pr = row / G::P, pc = row - pr * G::P;
+            const int hi = h0 - 1 + pr;
+            if (pc >= 1 && pc <= WI && hi >= 0 && hi < WI) prel[i] = ((pr * WI + pc) * p.Cin + (lc ^ ((row >> 1) & 7)) * 8) * 2;
+        }
+    }
+    const int xbase = (((n_img * WI + h0 - 1) * WI - 1) * p.Cin) * 2;      // (signed) byte offset of pixel (h0 - 1, -1)
+    // ---- weight DMA roles (as conv_igemm_dma_kernel): piece i of this wave = rows wave*8*BI + 8 i + lr of the B tile
+    int woff[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+        woff[i] = ((n0 + wave * 8 * BI + 8 * i + lr) * K + chunk * 8) * 2;
+    }
+    // ---- fragment reads. A: tile row (pixel) k -> patch row pp0 at tap (0, 0); per tap column s the row pp0 + s and its swizzle
+    uint32_t arow[MI][3], az[MI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int k = wm * WM + mi * 32 + frow;
+        const int i = k / WI, w = k - i * WI;
+        const int pp0 = k < G::KPIX ? i * G::P + w : 0;   // padded tile rows read the patch's (finite) first pixels; never stored
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            arow[mi][s2] = (uint32_t)(pp0 + s2) * CV_ROWB;
+            az[mi][s2] = (uint32_t)(((pp0 + s2) >> 1) & 7);
+        }
+    }
+    uint32_t bf[NI][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = wn * 64 + ni * 32 + frow;
+            bf[ni][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(bf[ni][kk]));
+        }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+#define CP_ISSUE_PATCH(cb, ps)                                                                                  \
+    {                                                                                                           \
+        const int cbo = xbase + (cb) * CV_BK * 2;                                                               \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < G::PPW; ++i) {                                                                      \
+            const int q = wave + 4 * i;                                                                         \
+            if (q < G::PPIECES) cp_dma16(rs_x, lds0 + (uint32_t)((ps) * G::PATCH + q * 1024), prel[i] == CV_OOB ? CV_OOB : cbo + prel[i], 0); \
+        }                                                                                                       \
+    }
+    // K-step (tap, cb) of the weights = columns (tap * cpk + cb) * 64 .. + 63 of the [Cout][R*S*Cin] matrix
+#define CP_ISSUE_B(tap, cb, bs)                                                                                 \
+    {                                                                                                           \
+        const int wso = ((tap) * p.cpk + (cb)) * CV_BK * 2;                                                     \
+        const uint32_t bb = lds0 + b_base + (uint32_t)((bs) * B_BYTES + wave * (BI * 1024));                    \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < BI; ++i) cp_dma16(rs_w, bb + i * 1024, woff[i], wso);                               \
+    }
+#define CP_MFMA_STEP(r_, s_, ps, bs)                                                                            \
+    {                                                                                                           \
+        const unsigned char* ab = smem + (ps) * G::PATCH + (r_) * (G::P * CV_ROWB);                             \
+        const unsigned char* bbs = smem + b_base + (bs) * B_BYTES;                                              \
+        _Pragma("unroll")                                                                                       \
+        for (int kk = 0; kk < 4; ++kk) {                                                                        \
+            bf16x8 a[MI], b[NI];                                                                                \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi)                                                                     \
+                a[mi] = *reinterpret_cast<const bf16x8*>(ab + arow[mi][s_] + ((((uint32_t)(kk * 2 + fhalf)) ^ az[mi][s_]) << 4)); \
+            _Pragma("unroll")                                                                                   \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(bbs + bf[ni][kk]);         \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi)                                                                     \
+                _Pragma("unroll")                                                                               \
+                for (int ni = 0; ni < NI; ++ni)                                                                 \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  \
+        }                                                                                                       \
+    }
+
+    CP_ISSUE_PATCH(0, 0);
+    CP_ISSUE_B(0, 0, 0);
+    cp_dma_wait();
+    __syncthreads();
+    int bs = 0;
+    for (int cb = 0; cb < p.cpk; ++cb) {
+        const int ps = cb & 1;
+        if (cb + 1 < p.cpk) CP_ISSUE_PATCH(cb + 1, ps ^ 1);       // next channel block's patch lands during this block's nine taps
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // next weight slice in flight during the MFMAs (the first slice of the next channel block after tap 8)
+            if (tap < 8) { CP_ISSUE_B(tap + 1, cb, bs ^ 1); }
+            else if (cb + 1 < p.cpk) { CP_ISSUE_B(0, cb + 1, bs ^ 1); }
+            CP_MFMA_STEP(tap / 3, tap % 3, ps, bs);
+            cp_dma_wait();
+            __syncthreads();
+            bs ^= 1;
+        }
+    }
+#undef CP_MFMA_STEP
+#undef CP_ISSUE_B
+#undef CP_ISSUE_PATCH
+    ConvP pe = p;
+    pe.M = m0 + G::KPIX;                                          // rows past the chunk's pixels are padding: not stored, not counted
+    cv_epilogue<BN>(pe, acc, smem, t, m0, n0, mt);
+}
+
+template <int WI> constexpr int cp_chunks_per_image() { return CpGeom<WI>::CPI; }
+
 }  // namespace
 
 extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
     const long long M = (long long)N * Ho * Wo;
     return (size_t)((M + CV_BM - 1) / CV_BM);
+}
+
+// 3x3 / stride 1 / pad 1 on a 56^2, 28^2 or 14^2 map: the patch-staged kernel, whose M tiles are chunks of whole image rows
+static int g_patch3x3_on();
+static int cp_width(int H, int W, int R, int S, int stride, int pad) {
+    return (g_patch3x3_on() && R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)) ? W : 0;
+}
+static int cp_chunks(int W) { return W == 56 ? 28 : W == 28 ? 7 : 2; }
+// A/B switch for tools and tests (process-wide, default on): off = those layers take the per-tap kernels again. Returns the
+// previous setting. Changes dir_conv_tile_rows accordingly — flip it only between whole forward/backward passes.
+static int g_patch3x3 = 1;
+extern "C" int dir_conv_set_patch3x3(int enabled) { const int prev = g_patch3x3; g_patch3x3 = enabled ? 1 : 0; return prev; }
+static int g_patch3x3_on() { return g_patch3x3; }
+
+// Rows of the per-tile statistics / BatchNorm-partial list of ONE launch with this geometry (the tiling depends on the kernel
+// the launch takes): what `stats` must hold for dir_conv_fwd* / dir_conv_dgrad_bnstats.
+extern "C" size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
+    const int cw = cp_width(H, W, R, S, stride, pad);
+    if (cw) return (size_t)N * cp_chunks(cw);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    return dir_conv_stats_rows(N, Ho, Wo);
 }
 
 extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
@@ -641,10 +873,11 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 }
 
 // A/B measurements and tests: the same convolution with the K-loop variant forced (0 = heuristic = dir_conv_fwd,
-// 1 = register-staged, 2 = LDS-DMA).
+// 1 = register-staged, 2 = LDS-DMA, 3 = patch-staged 3x3; 1 and 2 tile M by 128 rows: stats rows = dir_conv_stats_rows).
 extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                                     int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
-    DIR_RETURN_IF(variant < 0 || variant > 2, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > 3, DIR_EINVAL);
+    DIR_RETURN_IF(variant == 3 && !(R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)), DIR_EUNSUPPORTED);
     return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
 
@@ -750,6 +983,28 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int tile_n = wide ? 128 : 64;
     const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
+    const int cpw = (cls || variant == 1 || variant == 2) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
+    if (cpw) {
+        // patch-staged 3x3: M tiles = chunks of whole image rows
+        p.nblocks = N * cp_chunks(cpw) * p.ntn;
+        const int npatch = p.cpk > 1 ? 2 : 1;
+        const int prows = cpw == 56 ? 256 : cpw == 28 ? 192 : 144;
+        const int loop3 = npatch * prows * CV_ROWB + 2 * tile_n * CV_ROWB;
+        const int lds3 = loop3 > stage ? loop3 : stage;
+#define CP_LAUNCH(W_, BN_)                                                                                                    \
+        {                                                                                                                         \
+            static bool once_cp = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<W_, BN_>),         \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);            \
+            (void)once_cp;                                                                                                        \
+            hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);                       \
+        }
+        if (cpw == 56) { if (wide) CP_LAUNCH(56, 128) else CP_LAUNCH(56, 64) }
+        else if (cpw == 28) { if (wide) CP_LAUNCH(28, 128) else CP_LAUNCH(28, 64) }
+        else { if (wide) CP_LAUNCH(14, 128) else CP_LAUNCH(14, 64) }
+#undef CP_LAUNCH
+        DIR_LAUNCH_CHECK();
+        return DIR_OK;
+    }
     const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
     if (dma) {
         const int loop2 = 2 * (CV_BM * CV_ROWB + tile_n * CV_ROWB);

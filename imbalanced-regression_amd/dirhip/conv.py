@@ -49,7 +49,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     stats = None
     if want_stats:
-        rows = L.lib().dir_conv_stats_rows(n, ho, wo)
+        rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, stride, padding)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     if addend is not None:
         assert addend.shape == y.shape and addend.dtype == torch.bfloat16 and not want_stats
@@ -68,7 +68,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         # data gradient whose result is the `dout` of the BatchNorm behind bn_link: that node's backward reduction is formed in
         # the store loop (bn.BwdLink)
         assert stride == 1 and not want_stats and bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
-        rows = L.lib().dir_conv_stats_rows(n, ho, wo)
+        rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, 1, padding)
         part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
         L.check(L.lib().dir_conv_dgrad_bnstats(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
                                                cin, cout, r, s, padding, *_bn_link_args(bn_link), L.ptr(part),

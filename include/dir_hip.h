@@ -250,6 +250,14 @@ int dir_bn_apply(const void* x, const void* residual, const float* residual_coef
  * rotated, in/out-transposed weights.
  */
 size_t dir_conv_stats_rows(int N, int Ho, int Wo);
+/* Rows of that list for ONE launch of this geometry: dir_conv_stats_rows(N, Ho, Wo) for the kernels that tile M by 128 rows;
+ * N x (chunks of whole image rows per image) for the 3x3 / stride-1 / pad-1 layers on 56^2, 28^2, 14^2 maps, which run the
+ * patch-staged kernel (the input patch of a chunk is staged in LDS once per 64-channel block and all nine taps read it there,
+ * instead of nine shifted fetches of the same pixels).  Use this to size `stats` of dir_conv_fwd* / dir_conv_dgrad_bnstats. */
+size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
+/* A/B switch for tools and tests (process-wide, default 1): 0 = the 3x3 / stride-1 layers take the per-tap kernels again (and
+ * dir_conv_tile_rows answers accordingly).  Returns the previous setting; flip only between whole passes. */
+int dir_conv_set_patch3x3(int enabled);
 /* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,

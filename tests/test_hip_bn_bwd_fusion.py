@@ -65,7 +65,8 @@ def test_dgrad_epilogue_sums_vs_float64(n, cy, cx, hw, k, extras, recompute):
     y_plain = conv2d_igemm(dy, w, 1, k // 2, addend=addend, relu_mask=mask)
     assert torch.equal(y, y_plain)                                   # the stored gradient is untouched by the fusion
     part = link.partial
-    assert part is not None and part.shape == ((n * hw * hw + 127) // 128, 2, cx)
+    from dirhip import _lib as L
+    assert part is not None and part.shape == (L.lib().dir_conv_tile_rows(n, hw, hw, k, k, 1, k // 2), 2, cx)
     s0, s1 = _expected_sums(y, link)
     got = part.double().sum(0)
     # per-tile float32 accumulation of <= 128 terms: 1e-5 of the scale of the column sums

@@ -41,7 +41,7 @@ def main():
             xs = [torch.randn(B, ci, hh, hh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
             ys = [torch.empty(B, co, hout, hout, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
             w = (torch.randn(co, ci, k, k, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            rows = L.lib().dir_conv_stats_rows(B, hout, hout)
+            rows = max(L.lib().dir_conv_stats_rows(B, hout, hout), L.lib().dir_conv_tile_rows(B, hh, hh, k, k, s_, pad))
             stt = torch.empty(rows, 2, co, dtype=torch.float32, device=dev) if kind == "fwd" else None
             flop = 2.0 * B * hout * hout * co * ci * k * k
             roof_us = max(flop / 2.5e15, nbytes / 8e12) * 1e6
