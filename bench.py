@@ -190,7 +190,7 @@ def measured_peaks(device):
     return out
 
 
-FAMILIES = (("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
+FAMILIES = (("conv_igemm", "conv_igemm"), ("conv3x3_patch", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
             ("bn_", "batchnorm"), ("tail_", "tail"), ("fds_", "fds"), ("loss_", "loss"), ("scale_by_scalar", "loss"),
             ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"))
 
@@ -487,13 +487,14 @@ def main():
                                 "launches_per_step_in_that_pass": tj.get("launches_per_step")}
                 break
         result["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel (hand-written MFMA implicit GEMM): every forward and data-gradient "
-                                       "launch of the 52 conv layers of one training step, in situ",
+            "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_patch_kernel (hand-written MFMA implicit GEMM): every forward "
+                                       "and data-gradient launch of the 52 conv layers of one training step, in situ; their store loops also carry "
+                                       "the shortcut-gradient adds, ReLU masks and 43 of the 52 BatchNorm backward reductions",
             "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
             "frac_of_measured_peak": ach / peaks["bf16_mfma_TFs"], "traffic": None, "traffic_from_profiles": traffic_note,
             "launches_per_step": ig["launches_per_step"], "avg_launch_us": ig["us_per_step"] / max(1.0, ig["launches_per_step"]),
             "algorithmic_flop_per_step": alg_flop, "ms_per_step_in_this_kernel": ig["us_per_step"] / 1e3,
-            "method": "device time of every conv_igemm* launch over 4 whole training steps (profiler kernel trace), algorithmic "
+            "method": "device time of every conv_igemm* / conv3x3_patch* launch over 4 whole training steps (profiler kernel trace), algorithmic "
                       "FLOPs = 2 x (forward FLOPs of the 52 layers) = forward + data gradient; SURVEY.md §8d"}
         result["step_breakdown_in_situ"] = {"busy_ms_per_step": busy / 1e3, "wall_ms_per_step_train_only": dt_train / args.steps * 1e3,
                                             "families": {k: {"ms_per_step": v["us_per_step"] / 1e3, "launches_per_step": v["launches_per_step"],
