@@ -226,6 +226,17 @@ bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __r
     coef[C + c] = (float)((double)beta[c] - (double)running_mean[c] * (double)gamma[c] * rstd);
 }
 
+// One byte per 8-channel group of a ReLU output row: bit j = (the STORED value of channel j) > 0 — the mask of that ReLU's
+// backward at 1/16 of the bytes of the tensor itself (bf16 only; a positive float that rounds to bf16 zero counts as zero).
+template <typename T> __device__ __forceinline__ uint8_t relu_bits(const float (&o)[Vec<T>::N]);
+template <> __device__ __forceinline__ uint8_t relu_bits<float>(const float (&)[4]) { return 0; }
+template <> __device__ __forceinline__ uint8_t relu_bits<bf16_t>(const float (&o)[8]) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b |= (__uint_as_float(f2bf(o[j]) << 16) > 0.0f ? 1u : 0u) << j;
+    return (uint8_t)b;
+}
+
 // ---- forward: y = [relu]( x * a + b [+ residual] ) ---------------------------------------------------------
 // RES: 0 = no residual, 1 = residual tensor added as is, 2 = residual is itself the INPUT of a BatchNorm whose
 // normalisation (rcoef) is applied on the fly (projection shortcut: relu(bn3(x) + bn_d(r)), resnet.py:63-68, without
@@ -233,7 +244,7 @@ bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __r
 template <typename T, int RES, bool RELU>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t M, int C, BnGeom g,
-                const float* __restrict__ coef, const float* __restrict__ rcoef) {
+                const float* __restrict__ coef, const float* __restrict__ rcoef, uint8_t* __restrict__ bits) {
     constexpr int VEC = Vec<T>::N;
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
     const int c = blockIdx.y * g.ct + tg * VEC;
@@ -265,6 +276,7 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
                 v[u][j] = o;
             }
             Vec<T>::store(y + (M - 1 - (row + u * stride)) * C + c, v[u]);
+            if (RELU && bits) bits[((M - 1 - (row + u * stride)) * C + c) / 8] = relu_bits<T>(v[u]);
         }
     }
     for (; row < M; row += stride) {
@@ -280,6 +292,7 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
             v[j] = o;
         }
         Vec<T>::store(y + (M - 1 - row) * C + c, v);
+        if (RELU && bits) bits[((M - 1 - row) * C + c) / 8] = relu_bits<T>(v);
     }
 }
 
@@ -481,17 +494,17 @@ int prepare_impl(const void* x_, int64_t M, int C, const float* gamma, const flo
 
 template <typename T>
 int apply_impl(const void* x_, const void* res_, const float* rcoef, void* y_, int64_t M, int C, const float* coef, int relu,
-               hipStream_t s) {
+               hipStream_t s, uint8_t* bits = nullptr) {
     constexpr int VEC = Vec<T>::N;
     const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
     BnGeom g = bn_geom<VEC>(M, C);
     const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
-    if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
-    else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
-    else if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
-    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef);
+    if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    else if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -500,7 +513,7 @@ template <typename T>
 int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const float* gamma, const float* beta,
              float* running_mean, float* running_var, double momentum, double eps, int relu, bool training,
              float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, hipStream_t s,
-             const float* ext_partial = nullptr, int ext_rows = 0) {
+             const float* ext_partial = nullptr, int ext_rows = 0, uint8_t* bits = nullptr) {
     constexpr int VEC = Vec<T>::N;
     BnWs w = bn_ws<VEC>(ws, M, C);
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
@@ -512,7 +525,7 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
         hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(dir_cdiv(C, DIR_TPB)), dim3(DIR_TPB), 0, s, C, gamma, beta, running_mean, running_var, eps, w.coef);
         DIR_LAUNCH_CHECK();
     }
-    return apply_impl<T>(x_, res_, nullptr, y_, M, C, w.coef, relu, s);
+    return apply_impl<T>(x_, res_, nullptr, y_, M, C, w.coef, relu, s, bits);
 }
 
 template <typename T>
@@ -682,6 +695,29 @@ extern "C" int dir_bn_apply(const void* x, const void* residual, const float* re
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
     if (dtype == DIR_BF16) return apply_impl<bf16_t>(x, residual, residual_coef, y, M, C, coef, relu, dir_s(stream));
     return apply_impl<float>(x, residual, residual_coef, y, M, C, coef, relu, dir_s(stream));
+}
+
+// dir_bn_fwd_train[_partials] / dir_bn_apply that also emit the ReLU's backward mask as one bit per element (relu_bits
+// [M][C/8] bytes, bit j of byte (m, c/8) = y[m][8 (c/8) + j] > 0): the consumer that applies this ReLU's backward inside its
+// data-gradient store loop (dir_conv_dgrad_ex, relu_mask_bits) then reads M*C/8 bytes instead of the 2*M*C of y. bf16, relu != 0.
+extern "C" int dir_bn_fwd_train_bits(const void* x, const void* residual, void* y, int64_t M, int C, const float* partial,
+                                     int partial_rows, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, double momentum, double eps, float* save_mean, float* save_rstd,
+                                     void* relu_bits_out, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || !relu_bits_out, DIR_EINVAL);
+    DIR_RETURN_IF((running_mean == nullptr) != (running_var == nullptr) || (partial && partial_rows <= 0), DIR_EINVAL);
+    DIR_RETURN_IF(!bn_shape_ok(DIR_BF16, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    return fwd_impl<bf16_t>(x, residual, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, 1, true, save_mean, save_rstd,
+                            workspace, workspace_bytes, dir_s(stream), partial, partial_rows, static_cast<uint8_t*>(relu_bits_out));
+}
+
+extern "C" int dir_bn_apply_bits(const void* x, const void* residual, const float* residual_coef, void* y, int64_t M, int C,
+                                 const float* coef, void* relu_bits_out, dir_stream_t stream) {
+    DIR_RETURN_IF(!x || !y || !coef || (residual_coef && !residual) || !relu_bits_out, DIR_EINVAL);
+    DIR_RETURN_IF(!bn_shape_ok(DIR_BF16, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(y) || (residual && !dir_aligned16(residual)), DIR_EINVAL);
+    return apply_impl<bf16_t>(x, residual, residual_coef, y, M, C, coef, 1, dir_s(stream), static_cast<uint8_t*>(relu_bits_out));
 }
 
 // (internal, used by dir_pool.hip's fused stem tail) partial [rows][2][C] of (sum g, sum g*x) -> dgamma, dbeta, coef[3][C]

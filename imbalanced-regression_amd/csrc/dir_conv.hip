@@ -47,10 +47,11 @@ struct ConvP {
     // BatchNorm whose input is bnx (same [rows][Cout] geometry as y); `stats` then receives the per-tile partials (sum g, sum g*bnx)
     // of dir_bn_bwd's first pass. With bn_gamma: that BatchNorm is followed by a ReLU whose mask (bnx * a + b > 0, the forward's own
     // decision) is applied to g for the sums only (the stored gradient stays unmasked: the BatchNorm's apply pass masks it again).
+    const uint8_t* mask_bits; // the same ReLU mask as one bit per element ([M][Cout / 8] bytes, dir_bn_*_bits), instead of `mask`
     const uint16_t* bnx;
     const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_rstd;
 };
-struct ConvBn { const void* x; const float* gamma; const float* beta; const float* mean; const float* rstd; };
+struct ConvBn { const void* x; const float* gamma; const float* beta; const float* mean; const float* rstd; const void* mask_bits; };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
 constexpr int CV_DMA_MIN_KT = 32;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+20 % from 32 steps up, mixed at 16, slower below (profiles/r02_conv_variants.txt)
@@ -148,12 +149,14 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
         uint32_t orow[HALF];                                    // element offset of the row's chunk in y (and in bnx / addend / mask)
         uint32_t o2row[HALF];                                   // ... of its compact stride-2 addend, or ~0u
         uint4 v_add[HALF], v_mask[HALF], v_bnx[HALF];
+        uint32_t v_bits[HALF];
 #pragma unroll
         for (int ii = 0; ii < HALF; ++ii) {
             const int i = hh * HALF + ii;
             orow[ii] = (uint32_t)(go0 + (size_t)i * gstep);
             o2row[ii] = ~0u;
             v_add[ii] = v_mask[ii] = v_bnx[ii] = make_uint4(0u, 0u, 0u, 0u);
+            v_bits[ii] = 0xffu;
             if (full || m0 + srow + i * RPI < p.M) {
                 if (decode) {
                     const int m = m0 + srow + i * RPI;
@@ -168,6 +171,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                 }
                 if (p.addend) v_add[ii] = *reinterpret_cast<const uint4*>(p.addend + orow[ii]);
                 if (p.mask) v_mask[ii] = *reinterpret_cast<const uint4*>(p.mask + orow[ii]);
+                if (p.mask_bits) v_bits[ii] = p.mask_bits[orow[ii] >> 3];
                 if (p.bnx) v_bnx[ii] = *reinterpret_cast<const uint4*>(p.bnx + orow[ii]);
             }
         }
@@ -211,6 +215,15 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                     for (int q2 = 0; q2 < 4; ++q2) {
                         if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
                         if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                    }
+                    c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                }
+                if (p.mask_bits) {                              // the same decision, from the forward's bit per element
+                    uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        if (!(v_bits[ii] & (1u << (2 * q2)))) cw[q2] &= 0xffff0000u;
+                        if (!(v_bits[ii] & (2u << (2 * q2)))) cw[q2] &= 0x0000ffffu;
                     }
                     c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
                 }
@@ -917,7 +930,20 @@ extern "C" int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* 
                                       int pad, const void* bn_x, const float* bn_gamma, const float* bn_beta,
                                       const float* bn_mean, const float* bn_rstd, float* stats, dir_stream_t stream) {
     DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
-    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd};
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, nullptr};
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, 0, stream, &bn);
+}
+
+// The general stride-1 data gradient: dir_conv_dgrad_join (+ dir_conv_dgrad_bnstats when bn_x != NULL) with the ReLU mask given
+// either as the tensor itself (relu_mask) or as the bit mask dir_bn_fwd_train_bits / dir_bn_apply_bits emitted
+// (relu_mask_bits, [N*H*W][Cout / 8] bytes): 1/16 of the bytes for the same decision. At most one of the two.
+extern "C" int dir_conv_dgrad_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
+                                 const void* relu_mask_bits, void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad,
+                                 const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                 const float* bn_rstd, float* stats, dir_stream_t stream) {
+    DIR_RETURN_IF((bn_x == nullptr) != (stats == nullptr) || (bn_x && !dir_aligned16(bn_x)), DIR_EINVAL);
+    DIR_RETURN_IF(bn_gamma && (!bn_x || !bn_beta || !bn_mean || !bn_rstd), DIR_EINVAL);
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, relu_mask_bits};
     return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, 0, stream, &bn);
 }
 
@@ -925,7 +951,7 @@ extern "C" int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void*
                                          const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                                          const float* bn_rstd, float* stats, dir_stream_t stream) {
     DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
-    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd};
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, nullptr};
     return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, &bn, stats, stream);
 }
 
@@ -942,11 +968,12 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
-    const bool fwd_stats = stats && !bn;                                         // forward statistics are of the conv result alone
+    const bool fwd_stats = stats && !(bn && bn->x);                              // forward statistics are of the conv result alone
     DIR_RETURN_IF(addend_s2 && (!dir_aligned16(addend_s2) || fwd_stats), DIR_EINVAL);
     DIR_RETURN_IF(addend && (!dir_aligned16(addend) || fwd_stats), DIR_EINVAL);
     DIR_RETURN_IF(relu_mask && (!dir_aligned16(relu_mask) || fwd_stats), DIR_EINVAL);
-    DIR_RETURN_IF(bn && (!stats || !bn->x), DIR_EINVAL);
+    DIR_RETURN_IF(bn && ((stats != nullptr) != (bn->x != nullptr)), DIR_EINVAL);
+    DIR_RETURN_IF(bn && bn->mask_bits && relu_mask, DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % CV_BK != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(x) || !dir_aligned16(w) || !dir_aligned16(y), DIR_EINVAL);
@@ -963,6 +990,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     p.addend = static_cast<const uint16_t*>(addend);
     p.mask = static_cast<const uint16_t*>(relu_mask);
     p.addend2 = static_cast<const uint16_t*>(addend_s2);
+    p.mask_bits = bn ? static_cast<const uint8_t*>(bn->mask_bits) : nullptr;
     p.bnx = bn ? static_cast<const uint16_t*>(bn->x) : nullptr;
     p.bn_gamma = bn ? bn->gamma : nullptr; p.bn_beta = bn ? bn->beta : nullptr;
     p.bn_mean = bn ? bn->mean : nullptr; p.bn_rstd = bn ? bn->rstd : nullptr;

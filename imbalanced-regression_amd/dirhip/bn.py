@@ -47,7 +47,7 @@ class BwdLink:
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, training, partial,
-                deferred=None, link=None):
+                deferred=None, link=None, bits=None):
         if not x.is_cuda:
             raise L.DirHipError(f"bn_act: input on {x.device}; the fused BatchNorm runs only as HIP kernels (no CPU fallback)")
         x = _nhwc(x)
@@ -64,7 +64,13 @@ class _BNActFn(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=x.device)
             rstd = torch.empty(c, dtype=torch.float32, device=x.device)
-            if partial is not None:                  # statistics fused into the producing convolution's epilogue
+            if bits is not None:                     # + the ReLU's backward mask, one bit per element (deferred ReLU backward)
+                L.check(L.lib().dir_bn_fwd_train_bits(L.ptr(x), L.ptr(residual), L.ptr(y), m, c, L.ptr(partial),
+                                                      0 if partial is None else partial.shape[0], L.ptr(gamma), L.ptr(beta),
+                                                      L.ptr(running_mean), L.ptr(running_var), float(momentum), float(eps),
+                                                      L.ptr(mean), L.ptr(rstd), L.ptr(bits), L.ptr(ws), ws.numel(), stream),
+                        "dir_bn_fwd_train_bits")
+            elif partial is not None:                # statistics fused into the producing convolution's epilogue
                 L.check(L.lib().dir_bn_fwd_train_partials(L.ptr(x), L.ptr(residual), L.ptr(y), code, m, c, L.ptr(partial),
                                                           partial.shape[0], L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
                                                           L.ptr(running_var), float(momentum), float(eps), int(relu),
@@ -130,7 +136,7 @@ class _BNActFn(torch.autograd.Function):
                                        L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "dir_bn_bwd")
         if dres is None and ctx.has_res:
             dres = dout
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNJoinFn(torch.autograd.Function):
@@ -140,7 +146,7 @@ class _BNJoinFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, momentum, eps, partial, r, gamma_r, beta_r, rm_r, rv_r, momentum_r, eps_r,
-                partial_r, relu, deferred):
+                partial_r, relu, deferred, bits=None):
         x, r = _nhwc(x), _nhwc(r)
         if r.dtype != x.dtype:
             r = r.to(x.dtype)
@@ -160,8 +166,12 @@ class _BNJoinFn(torch.autograd.Function):
             L.check(L.lib().dir_bn_prepare_train(L.ptr(t), code, m, c, L.ptr(part), 0 if part is None else part.shape[0],
                                                  L.ptr(g_), L.ptr(b_), L.ptr(rm_), L.ptr(rv_), float(mom), float(ep), L.ptr(mu),
                                                  L.ptr(rs), L.ptr(cf), L.ptr(ws), ws.numel(), stream), "dir_bn_prepare_train")
-        L.check(L.lib().dir_bn_apply(L.ptr(x), L.ptr(r), L.ptr(coef_r), L.ptr(y), code, m, c, L.ptr(coef), int(relu), stream),
-                "dir_bn_apply")
+        if bits is not None and relu:
+            L.check(L.lib().dir_bn_apply_bits(L.ptr(x), L.ptr(r), L.ptr(coef_r), L.ptr(y), m, c, L.ptr(coef), L.ptr(bits), stream),
+                    "dir_bn_apply_bits")
+        else:
+            L.check(L.lib().dir_bn_apply(L.ptr(x), L.ptr(r), L.ptr(coef_r), L.ptr(y), code, m, c, L.ptr(coef), int(relu), stream),
+                    "dir_bn_apply")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, r, gamma_r, beta_r, mean_r, rstd_r, y if relu else None)
         ctx.relu = bool(relu)
         ctx.deferred = deferred
@@ -196,7 +206,28 @@ class _BNJoinFn(torch.autograd.Function):
         L.check(L.lib().dir_bn_bwd(L.ptr(g), L.ptr(r), None, L.ptr(dr), None, code, m, c, L.ptr(gamma_r), L.ptr(beta_r),
                                    L.ptr(mean_r), L.ptr(rstd_r), L.ptr(dgamma_r), L.ptr(dbeta_r), 0, L.ptr(ws), ws.numel(), stream),
                 "dir_bn_bwd")
-        return (dx, dgamma, dbeta, None, None, None, None, None, dr, dgamma_r, dbeta_r, None, None, None, None, None, None, None)
+        return (dx, dgamma, dbeta, None, None, None, None, None, dr, dgamma_r, dbeta_r, None, None, None, None, None, None, None, None)
+
+
+# The deferred ReLU backward reads its mask as one bit per element (emitted by the forward) instead of the bf16 tensor itself.
+# Off = the tensor (tests and tools compare the two).
+_RELU_BITS = [True]
+
+
+def set_relu_bits(enabled):
+    """Returns the previous setting."""
+    prev = _RELU_BITS[0]
+    _RELU_BITS[0] = bool(enabled)
+    return prev
+
+
+def _relu_bits_for(x):
+    """Buffer for the one-bit-per-element ReLU mask of a bf16 NHWC result shaped like ``x`` (``[N*H*W][C/8]`` bytes), or None
+    where the kernels do not emit it (float32 parity mode, channel counts that are not a multiple of 8)."""
+    if not _RELU_BITS[0] or x.dtype != torch.bfloat16 or not x.is_cuda or x.shape[1] % 8:
+        return None
+    n, c, h, w = x.shape
+    return torch.empty((n * h * w, c // 8), dtype=torch.uint8, device=x.device)
 
 
 def _count_batch(bn):
@@ -216,11 +247,14 @@ def bn_join(x, bn, partial, r, bn_r, partial_r, relu=True, defer_relu_grad=False
     _count_batch(bn_r)
     deferred = [False] if (defer_relu_grad and relu and torch.is_grad_enabled()) else None
     trs, trs_r = bn.track_running_stats, bn_r.track_running_stats
+    bits = _relu_bits_for(x) if deferred is not None else None
     y = _BNJoinFn.apply(x, bn.weight, bn.bias, bn.running_mean if trs else None, bn.running_var if trs else None, bn.momentum,
                         bn.eps, partial, r, bn_r.weight, bn_r.bias, bn_r.running_mean if trs_r else None,
-                        bn_r.running_var if trs_r else None, bn_r.momentum, bn_r.eps, partial_r, relu, deferred)
+                        bn_r.running_var if trs_r else None, bn_r.momentum, bn_r.eps, partial_r, relu, deferred, bits)
     if deferred is not None:
         y._dir_relu_flag = deferred
+        if bits is not None:
+            y._dir_relu_bits = bits
     return y
 
 
@@ -245,14 +279,17 @@ def bn_act(x, bn, relu=True, residual=None, partial=None, defer_relu_grad=False,
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     deferred = [False] if (defer_relu_grad and relu and training and torch.is_grad_enabled()) else None
+    bits = _relu_bits_for(x) if deferred is not None else None
     link = None
     if fuse_bwd_stats and training and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and x.is_cuda \
             and (residual is None or (relu and deferred is not None)):
         link = BwdLink()
     y = _BNActFn.apply(x, bn.weight, bn.bias, residual, rm, rv, bn.momentum, bn.eps, relu, training,
-                       partial if training else None, deferred, link)
+                       partial if training else None, deferred, link, bits)
     if deferred is not None:
         y._dir_relu_flag = deferred
+        if bits is not None:
+            y._dir_relu_bits = bits
     if link is not None:
         y._dir_bn_link = link
     return y

@@ -33,7 +33,8 @@ def _bn_link_args(link):
             L.ptr(link.rstd) if g else None)
 
 
-def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None, bn_link=None):
+def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None, bn_link=None,
+                 relu_bits=None):
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -64,16 +65,23 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         assert addend_s2.shape == (n, cout, ho // 2, wo // 2) and addend_s2.dtype == torch.bfloat16 and not want_stats and stride == 1
         if not addend_s2.is_contiguous(memory_format=torch.channels_last):
             addend_s2 = addend_s2.contiguous(memory_format=torch.channels_last)
-    if bn_link is not None:
+    if bn_link is not None or relu_bits is not None:
         # data gradient whose result is the `dout` of the BatchNorm behind bn_link: that node's backward reduction is formed in
-        # the store loop (bn.BwdLink)
-        assert stride == 1 and not want_stats and bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
-        rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, 1, padding)
-        part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
-        L.check(L.lib().dir_conv_dgrad_bnstats(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
-                                               cin, cout, r, s, padding, *_bn_link_args(bn_link), L.ptr(part),
-                                               L.stream_ptr(x.device)), "dir_conv_dgrad_bnstats")
-        bn_link.partial = part
+        # the store loop (bn.BwdLink); relu_bits: the ReLU mask as the bit-per-element buffer the forward emitted for it
+        assert stride == 1 and not want_stats and (relu_bits is None or relu_mask is None)
+        part, bn_args = None, (None, None, None, None, None)
+        if bn_link is not None:
+            assert bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
+            rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, 1, padding)
+            part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+            bn_args = _bn_link_args(bn_link)
+        if relu_bits is not None:
+            assert relu_bits.dtype == torch.uint8 and relu_bits.numel() * 8 == y.numel()
+        L.check(L.lib().dir_conv_dgrad_ex(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(relu_bits), L.ptr(y),
+                                          n, h, wd, cin, cout, r, s, padding, *bn_args, L.ptr(part), L.stream_ptr(x.device)),
+                "dir_conv_dgrad_ex")
+        if bn_link is not None:
+            bn_link.partial = part
         return y
     if addend_s2 is not None:
         L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
@@ -131,10 +139,11 @@ class _ConvFn(torch.autograd.Function):
     (odd-sized maps) use the general float32 data gradient of ``conv_f32`` — never a library kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input, bn_link=None):
+    def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input, bn_link=None, relu_bits=None):
         ctx.stride, ctx.padding = stride, padding
         ctx.alias_input = alias_input
         ctx.bn_link = bn_link                    # bn.BwdLink of the BatchNorm that produced x (its backward reduction is ours)
+        ctx.relu_bits = relu_bits if relu_input else None      # x > 0 as one bit per element (bn._relu_bits_for), if the forward made it
         # relu_input: x is the output of a relu(bn(.) + shortcut) node that was promised its gradient with the ReLU
         # backward already applied (bn.bn_act(defer_relu_grad=True)): the data gradient is masked with x > 0 on store
         ctx.relu_input = relu_input
@@ -158,7 +167,7 @@ class _ConvFn(torch.autograd.Function):
         x, w16, w16_rot = ctx.saved_tensors
         if dy is None:                                                           # only the alias output was used
             assert not ctx.relu_input
-            return dalias, None, None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None, None, None
         link = ctx.bn_link
         if dalias is not None and dalias.dtype != torch.bfloat16:
             dalias = dalias.to(torch.bfloat16)
@@ -170,8 +179,9 @@ class _ConvFn(torch.autograd.Function):
         if need_dx and w16_rot is not None and ctx.stride == 1:
             # data gradient of a stride-1 convolution = the SAME implicit GEMM on dY with the 180-degree rotated,
             # in/out-transposed weights and padding R-1-pad
+            bits = ctx.relu_bits
             dx = conv2d_igemm(dy, w16_rot, 1, w16.shape[2] - 1 - ctx.padding, addend=dalias,
-                              relu_mask=x if ctx.relu_input else None, bn_link=link)
+                              relu_mask=x if (ctx.relu_input and bits is None) else None, bn_link=link, relu_bits=bits)
             dalias = None
             need_dx = False
         dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
@@ -199,7 +209,7 @@ class _ConvFn(torch.autograd.Function):
             dx = dalias if dx is None else dx + dalias
             if link is not None:
                 link.partial = None                                              # the sums were of an incomplete gradient
-        return dx, dw, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None
 
 
 class _ProjectionPairFn(torch.autograd.Function):
@@ -210,10 +220,11 @@ class _ProjectionPairFn(torch.autograd.Function):
     of the previous block's output. No strided transposed convolution, no zero fill, no gradient-add kernel."""
 
     @staticmethod
-    def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input, bn_link=None):
+    def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input, bn_link=None, relu_bits=None):
         ctx.set_materialize_grads(False)
         ctx.stride_d, ctx.relu_input = stride_d, relu_input
         ctx.bn_link = bn_link
+        ctx.relu_bits = relu_bits if relu_input else None
         if want_stats:
             y1, s1 = conv2d_igemm(x, w1_16, 1, 0, want_stats=True)
             yd, sd = conv2d_igemm(x, wd_16, stride_d, 0, want_stats=True)
@@ -235,20 +246,21 @@ class _ProjectionPairFn(torch.autograd.Function):
                 t = t.to(torch.bfloat16)
             return t.contiguous(memory_format=torch.channels_last)
         dy1, dyd = prep(dy1), prep(dyd)
-        mask = x if ctx.relu_input else None
+        bits = ctx.relu_bits
+        mask = x if (ctx.relu_input and bits is None) else None
         compact = conv2d_igemm(dyd, wd_rot, 1, 0) if dyd is not None else None
         if dy1 is None:
             raise L.DirHipError("projection pair: conv1's output received no gradient")
         link = ctx.bn_link
         if compact is None:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, relu_mask=mask, bn_link=link)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, relu_mask=mask, bn_link=link, relu_bits=bits)
         elif ctx.stride_d == 1:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask, bn_link=link)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask, bn_link=link, relu_bits=bits)
         else:
-            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask, bn_link=link)
+            dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask, bn_link=link, relu_bits=bits)
         dw1 = conv2d_wgrad(dy1, x, 1, 1, 0)
         dwd = conv2d_wgrad(dyd, x, 1, ctx.stride_d, 0) if dyd is not None else None
-        return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None, None
+        return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None, None, None
 
 
 # Generation counter of "the weights may have changed": fused / multi-tensor optimizer kernels update parameters
@@ -386,7 +398,7 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
                                  and (relu_input if link.needs_relu_claim else not alias_input)):
         link = None
     y, stats, alias = _ConvFn.apply(x, w, w16, w16_rot if grad_mode else None, conv.stride[0], conv.padding[0],
-                                    want_stats, aliasing, relu_input, link)
+                                    want_stats, aliasing, relu_input, link, getattr(x, "_dir_relu_bits", None) if relu_input else None)
     if alias_input:
         return y, stats, (alias if alias is not None else x)
     return y, stats
@@ -418,7 +430,7 @@ def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
                                  and (relu_input or not link.needs_relu_claim)):
         link = None
     return _ProjectionPairFn.apply(x, conv1.weight, w1_16, w1_rot, conv_d.weight, wd_16, wd_rot, conv_d.stride[0], want_stats,
-                                   relu_input, link)
+                                   relu_input, link, getattr(x, "_dir_relu_bits", None) if relu_input else None)
 
 
 def projection_pair_ok(conv1, conv_d, x=None):

@@ -217,6 +217,16 @@ int dir_bn_bwd(const void* dout, const void* x, const void* out, void* dx, void*
                int64_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                const float* save_rstd, float* dgamma, float* dbeta, int relu, void* workspace,
                size_t workspace_bytes, dir_stream_t stream);
+/* dir_bn_fwd_train[_partials] (relu = 1; partial may be NULL) and dir_bn_apply (relu = 1) for bf16 tensors that ALSO emit the
+ * ReLU's backward mask as one bit per element: relu_bits_out [M][C / 8] bytes, bit j of byte (m, g) = y[m][8 g + j] > 0.  The
+ * block outputs relu(bn3(.) + shortcut) of imdb-wiki-dir/resnet.py:66-68 are masks of the next block's data gradient
+ * (dir_conv_dgrad_ex): reading the bits instead of the tensor saves 15/16 of that read. */
+int dir_bn_fwd_train_bits(const void* x, const void* residual, void* y, int64_t M, int C, const float* partial, int partial_rows,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, double momentum,
+                          double eps, float* save_mean, float* save_rstd, void* relu_bits_out, void* workspace,
+                          size_t workspace_bytes, dir_stream_t stream);
+int dir_bn_apply_bits(const void* x, const void* residual, const float* residual_coef, void* y, int64_t M, int C,
+                      const float* coef, void* relu_bits_out, dir_stream_t stream);
 /* dir_bn_bwd minus its first pass: the per-channel sums of g and g*x arrive as `partial` [partial_rows][2][C] f32 from the
  * data-gradient kernel that produced dout (dir_conv_dgrad_bnstats / dir_conv_dgrad_s2_bnstats), so dout and x are read once
  * (apply pass) instead of twice.  relu != 0: ReLU layer without residual, mask recomputed from x (as dir_bn_bwd with
@@ -308,6 +318,14 @@ int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* addend, con
                            void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, const void* bn_x,
                            const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_rstd,
                            float* stats, dir_stream_t stream);
+/* The general stride-1 data gradient: dir_conv_dgrad_join, plus dir_conv_dgrad_bnstats when bn_x != NULL (then stats != NULL),
+ * with the ReLU backward mask given either as the tensor itself (relu_mask, as above) or as the bit mask that
+ * dir_bn_fwd_train_bits / dir_bn_apply_bits emitted for it (relu_mask_bits, [N*H*W][Cout / 8] bytes, bit j of a byte = channel
+ * 8 b + j was positive): 1/16 of the bytes for the same decision.  At most one of the two. */
+int dir_conv_dgrad_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
+                      const void* relu_mask_bits, void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad,
+                      const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                      const float* bn_rstd, float* stats, dir_stream_t stream);
 int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
                               const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                               const float* bn_rstd, float* stats, dir_stream_t stream);

@@ -295,6 +295,52 @@ def test_deferred_relu_backward_is_bit_identical():
         assert torch.equal(a, b)
 
 
+def test_relu_bit_mask_is_bit_identical_to_the_tensor_mask():
+    """The deferred ReLU backward reads its mask as one bit per element emitted by the forward (dir_bn_fwd_train_bits /
+    dir_bn_apply_bits -> dir_conv_dgrad_ex) instead of the block output itself: same decisions, so identical gradients — over
+    an identity block, a stride-1 projection pair and a stride-2 one (the join's bits), chained."""
+    import torch.nn as nn
+    from dirhip import bn as B
+    from dirhip import resnet as R
+    torch.manual_seed(4)
+    down1 = nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+    down2 = nn.Sequential(nn.Conv2d(256, 512, 1, stride=2, bias=False), nn.BatchNorm2d(512))
+    blocks = [R.Bottleneck(64, 64, downsample=down1), R.Bottleneck(256, 64), R.Bottleneck(256, 128, stride=2, downsample=down2),
+              R.Bottleneck(512, 128)]
+    blocks = [b.cuda().to(memory_format=torch.channels_last) for b in blocks]
+    params = [p for b in blocks for p in b.parameters()]
+    g = torch.Generator(device="cuda").manual_seed(14)
+    x0 = torch.relu(torch.randn(6, 64, 28, 28, device="cuda", generator=g)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(6, 512, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(bits):
+        prev = B.set_relu_bits(bits)
+        try:
+            for p in params:
+                p.grad = None
+            for b in blocks:
+                for m in b.modules():
+                    if isinstance(m, nn.BatchNorm2d):
+                        m.reset_running_stats()
+            x = x0.clone().requires_grad_(True)
+            y = x * 1.0
+            seen = []
+            for b in blocks:
+                y = b(y)
+                seen.append(hasattr(y, "_dir_relu_bits"))
+            y.backward(dy)
+        finally:
+            B.set_relu_bits(prev)
+        return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params], seen
+
+    y1, gx1, gp1, seen1 = run(True)
+    y0, gx0, gp0, seen0 = run(False)
+    assert all(seen1) and not any(seen0)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert torch.equal(a, b)
+
+
 def test_dgrad_join_adds_compact_stride2_gradient_at_even_pixels():
     """dir_conv_dgrad_join: conv + up2(compact) must equal the dense result plus the zero-upsampled compact tensor, bitwise."""
     from dirhip.conv import conv2d_igemm
