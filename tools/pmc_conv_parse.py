@@ -13,7 +13,7 @@ for cin, cout, k, st, h, cnt in RESNET50_CONVS:
 out = {"batch": B, "launches_per_step": sum(c for c, _ in cfgs), "algorithmic_bytes_per_step": sum(c * b for c, b in cfgs)}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(sys.argv[1], f"*{name}*counter_collection.csv"))
-    rows = [r for r in csv.DictReader(open(files[0])) if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows = [r for r in csv.DictReader(open(files[0])) if ("conv_igemm" in r["Kernel_Name"] or "conv3x3_patch" in r["Kernel_Name"]) and r["Counter_Name"] == name]
     vals = [float(r["Counter_Value"]) for r in rows]
     assert len(vals) == 2 * len(cfgs), (len(vals), len(cfgs))
     last = vals[1::2]                                        # second launch of each configuration

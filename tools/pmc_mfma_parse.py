@@ -23,7 +23,7 @@ for cin, cout, k, st, h, cnt in RESNET50_CONVS:
     cfgs.append((f"{cin}->{cout} k{k} s{st} H{h} fwd", cnt, 2.0 * B * ho * ho * cout * cin * k * k))
     if st == 1:
         cfgs.append((f"{cout}->{cin} k{k} s1 H{ho} dgrad", cnt, 2.0 * B * ho * ho * cout * cin * k * k))
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_igemm" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_igemm" in r["Kernel_Name"] or "conv3x3_patch" in r["Kernel_Name"]]
 by_disp = collections.OrderedDict()
 for r in rows:
     d = by_disp.setdefault(r["Dispatch_Id"], {"_t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
