@@ -2,9 +2,11 @@
 
 Same constructor and ``__getitem__ -> (img f32[3,S,S], label f32[1], weight f32[1])`` contract; ``.weights`` comes
 from the native LDS routine (``dirhip.lds.prepare_weights`` -> ``dir_lds_weights``, bit-exact with the reference's
-numpy/scipy arithmetic). Image decoding/augmentation is host-side PIL + numpy (the reference uses torchvision
-transforms, which this image does not ship): Resize -> RandomCrop(pad 16) -> RandomHorizontalFlip -> [0,1] ->
-Normalize(.5, .5) (datasets.py:38-53). ``SyntheticAgeDataset`` produces device-resident random batches with the
+numpy/scipy arithmetic). Image decoding and Resize are host-side PIL (the reference uses torchvision
+transforms, which this image does not ship); the rest of the transform chain — RandomCrop(pad 16) -> RandomHorizontalFlip ->
+[0,1] -> Normalize(.5, .5) (datasets.py:38-53) — runs either on the host (numpy, the default ``__getitem__`` contract) or,
+with ``raw=True`` + ``DeviceAugment``, as ONE HIP launch per batch on the uint8 images (``dir_augment_u8``):
+a quarter of the host->device bytes, no float32 round trip, bf16 NHWC output straight into the MFMA stem. ``SyntheticAgeDataset`` produces device-resident random batches with the
 same label/weight semantics for benchmarking without image files.
 """
 import logging
@@ -19,9 +21,51 @@ from .lds import prepare_weights
 print = logging.info
 
 
+def draw_augment_params(n, pad=16, generator=None):
+    """The random draws of RandomCrop(S, padding=pad) + RandomHorizontalFlip for ``n`` images, per image in torchvision's order
+    (top, then left — both uniform on [0, 2 pad] —, then the flip coin): int32 ``[n, 3]`` = (top, left, flip) on the host."""
+    out = torch.empty((n, 3), dtype=torch.int32)
+    for i in range(n):
+        out[i, 0] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))
+        out[i, 1] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))
+        out[i, 2] = int(float(torch.rand(1, generator=generator)) < 0.5)
+    return out
+
+
+class DeviceAugment:
+    """GPU side of the transform chain for ``raw=True`` datasets: ``aug(u8)`` takes a uint8 ``[B, S, S, 3]`` device batch (decoded,
+    resized) and returns the network input, a channels_last ``[B, 3, S, S]`` tensor (float32, or bf16 for the autocast path),
+    augmented like datasets.py:40-46 when ``train`` (draws from ``draw_augment_params``; pass ``params`` to replay) and like
+    datasets.py:48-52 otherwise. One HIP launch; no CPU fallback."""
+
+    def __init__(self, img_size, train=True, pad=16, dtype=torch.float32, generator=None):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.img_size, self.train, self.pad, self.dtype, self.generator = img_size, train, pad, dtype, generator
+
+    def __call__(self, u8, params=None):
+        from . import _lib as L
+        if not u8.is_cuda:
+            raise L.DirHipError(f"DeviceAugment: batch on {u8.device}; the augmentation kernel runs only on the GPU")
+        assert u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[1] == u8.shape[2] == self.img_size and u8.shape[3] == 3
+        u8 = u8.contiguous()
+        b, s = u8.shape[0], u8.shape[1]
+        if self.train and params is None:
+            params = draw_augment_params(b, self.pad, self.generator)
+        if params is not None:
+            params = torch.as_tensor(params, dtype=torch.int32).to(u8.device).contiguous()
+            assert params.shape == (b, 3)
+        out = torch.empty((b, s, s, 3), dtype=self.dtype, device=u8.device)
+        L.check(L.lib().dir_augment_u8(L.ptr(u8), L.ptr(params), L.ptr(out), L.DIR_BF16 if self.dtype == torch.bfloat16 else L.DIR_F32,
+                                       b, s, self.pad, L.stream_ptr(u8.device)), "dir_augment_u8")
+        return out.permute(0, 3, 1, 2)                          # [B, 3, S, S] view with channels_last strides
+
+
 class _AgeDataset(data.Dataset):
     def __init__(self, df, data_dir, img_size, split='train', reweight='none',
-                 lds=False, lds_kernel='gaussian', lds_ks=5, lds_sigma=2):
+                 lds=False, lds_kernel='gaussian', lds_ks=5, lds_sigma=2, raw=False):
+        # raw=True (extension): __getitem__ returns the decoded, resized uint8 HWC image instead of the transformed float
+        # tensor; the rest of the transform chain then runs on the GPU (DeviceAugment)
+        self.raw = raw
         self.df = df
         self.data_dir = data_dir
         self.img_size = img_size
@@ -43,13 +87,15 @@ class _AgeDataset(data.Dataset):
             from PIL import Image
             img = img.resize((size, size), Image.BILINEAR)
             arr = np.asarray(img, dtype=np.uint8)
+            if self.raw:
+                return torch.from_numpy(np.array(arr, copy=True))              # uint8 [S, S, 3]; augmentation on the GPU
             if train:
+                top, left, flip = (int(v) for v in draw_augment_params(1)[0])
                 arr = np.pad(arr, ((16, 16), (16, 16), (0, 0)))                 # RandomCrop(size, padding=16)
-                top, left = np.random.randint(0, 33), np.random.randint(0, 33)
                 arr = arr[top:top + size, left:left + size]
-                if np.random.rand() < 0.5:                                       # RandomHorizontalFlip
+                if flip:                                                         # RandomHorizontalFlip
                     arr = arr[:, ::-1]
-            out = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div_(255.)
+            out = torch.from_numpy(np.array(arr, copy=True)).permute(2, 0, 1).float().div_(255.)
             return out.sub_(0.5).div_(0.5)                                       # Normalize([.5]*3, [.5]*3)
         return transform
 

@@ -84,6 +84,8 @@ def build_parser(dataset_default='imdb_wiki'):
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic samples (no image files)')
     p.add_argument('--amp', type=str, default='bf16', choices=['bf16', 'fp32'], help='conv-stack precision')
     p.add_argument('--max_steps', type=int, default=0, help='truncate every epoch to this many steps (0 = full)')
+    p.add_argument('--gpu_augment', action='store_true', help='image files only: the DataLoader yields decoded, resized uint8 images and '
+                   'RandomCrop / flip / ToTensor / Normalize run as one HIP kernel per batch (dir_augment_u8) instead of per image on the host')
     p.add_argument('--overwrite', action='store_true', help='delete an existing run folder of the same name (the reference asks on '
                    'the terminal; without a terminal nothing is deleted unless this flag is given)')
     p.set_defaults(augment=True)
@@ -114,10 +116,15 @@ class _NullTB:
         pass
 
 
-def _loader_batches(loader, device):
+def _loader_batches(loader, device, augment=None):
+    """``augment``: a ``datasets.DeviceAugment`` when the dataset is in raw mode — the uint8 batch goes over PCIe (a quarter of the
+    float32 bytes) and crop / flip / normalise / cast run as one kernel on the GPU."""
     for batch in loader:
         inputs, targets, weights = batch[0], batch[1], batch[2]
-        out = (inputs.to(device, non_blocking=True), targets.to(device, non_blocking=True), weights.to(device, non_blocking=True))
+        inputs = inputs.to(device, non_blocking=True)
+        if augment is not None:
+            inputs = augment(inputs)
+        out = (inputs, targets.to(device, non_blocking=True), weights.to(device, non_blocking=True))
         yield out + ((batch[3].bool(),) if len(batch) > 3 else ())
 
 
@@ -291,21 +298,25 @@ def run(argv=None, dataset_default='imdb_wiki'):
         df_train, df_val, df_test = df[df['split'] == 'train'], df[df['split'] == 'val'], df[df['split'] == 'test']
         train_labels = df_train['age']
         cls = datasets.IMDBWIKI if args.dataset == 'imdb_wiki' else datasets.AgeDB
+        raw = bool(args.gpu_augment)
         train_set = cls(data_dir=args.data_dir, df=df_train, img_size=args.img_size, split='train', reweight=args.reweight,
-                        lds=args.lds, lds_kernel=args.lds_kernel, lds_ks=args.lds_ks, lds_sigma=args.lds_sigma)
-        val_set = cls(data_dir=args.data_dir, df=df_val, img_size=args.img_size, split='val')
-        test_set = cls(data_dir=args.data_dir, df=df_test, img_size=args.img_size, split='test')
+                        lds=args.lds, lds_kernel=args.lds_kernel, lds_ks=args.lds_ks, lds_sigma=args.lds_sigma, raw=raw)
+        val_set = cls(data_dir=args.data_dir, df=df_val, img_size=args.img_size, split='val', raw=raw)
+        test_set = cls(data_dir=args.data_dir, df=df_test, img_size=args.img_size, split='test', raw=raw)
         n_train = len(train_set)
+        aug_dtype = torch.bfloat16 if args.amp == 'bf16' else torch.float32
+        aug_train = datasets.DeviceAugment(args.img_size, train=True, dtype=aug_dtype) if raw else None
+        aug_eval = datasets.DeviceAugment(args.img_size, train=False, dtype=aug_dtype) if raw else None
 
         def train_batches(epoch):
             idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
             loader = DataLoader(_ShardSubset(train_set, idx.tolist(), valid.tolist()), batch_size=args.batch_size, shuffle=True,
                                 num_workers=args.workers, pin_memory=True, drop_last=False)
-            return lambda: _loader_batches(loader, device)
+            return lambda: _loader_batches(loader, device, aug_train)
 
         def eval_batches(ds):
             loader = DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, pin_memory=True)
-            return lambda: _loader_batches(loader, device)
+            return lambda: _loader_batches(loader, device, aug_eval)
         steps_per_epoch = (len(shard_indices(n_train, rank, world)) + args.batch_size - 1) // args.batch_size
         n_val = (len(val_set) + args.batch_size - 1) // args.batch_size
     print(f"Training data size: {len(train_set)}")

@@ -369,6 +369,15 @@ int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, in
                       size_t workspace_bytes, dir_stream_t stream);
 /* dw[i] = sum over s < splits, in order, of part[s * n + i] (the reduction pass of both weight-gradient forms); n % 4 == 0. */
 int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float* dw, dir_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * §8f-4  training-time image augmentation on the GPU.  Replaces, for a decoded and resized uint8 batch, the transform chain
+ * of imdb-wiki-dir/datasets.py:38-53 behind Resize: RandomCrop(S, padding = pad, fill 0) -> RandomHorizontalFlip ->
+ * ToTensor -> Normalize([.5]*3, [.5]*3) (torchvision.transforms; not vendored in the reference, semantics restated in
+ * oracle/augment_oracle.py).  img [B, S, S, 3] uint8 (HWC); params [B][3] int32 = (top, left, flip) with top, left in
+ * [0, 2 pad] — the draws RandomCrop.get_params / RandomHorizontalFlip make — or NULL for the evaluation transform (no crop,
+ * no flip); out [B, S, S, 3] float32 or bf16 (dtype) = a channels_last [B, 3, S, S] tensor, float32 arithmetic exactly as
+ * ToTensor / Normalize execute it ((u8 / 255 - 0.5) / 0.5; padding pixels -> -1). */
+int dir_augment_u8(const void* img, const int* params, void* out, int dtype, int B, int S, int pad, dir_stream_t stream);
 /* Test probe of the hardware-transposing LDS read the 3x3 weight gradient is built on: LDS holds the uint16 ramp 0, 1, 2, ...
  * (8192 elements); lane l of ONE wavefront issues ds_read_b64_tr_b16 at byte address addr_bytes[l] (8-byte aligned) and
  * out[4 l .. 4 l + 3] receives its four 16-bit results. */
