@@ -323,6 +323,29 @@ def fds_kernel_rooflines(device):
     return out
 
 
+def pmc_traffic(batch):
+    """HBM bytes of the conv forward / data-gradient launches from the hardware counters: two rocprofv3 --pmc passes (FETCH_SIZE,
+    WRITE_SIZE — separate runs, counter collection only next to --kernel-trace) over tools/pmc_conv_pass.py as child processes,
+    parsed by tools/pmc_conv_parse.py (units and the gfx950 FETCH_SIZE correction as MI355X_MICROARCH.md prescribes)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        raise FileNotFoundError("rocprofv3")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_conv_parse
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", name, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, name), "-o", name, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_conv_pass.py"), str(batch)]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if p.returncode != 0:
+                raise RuntimeError(f"rocprofv3 --pmc {name}: rc {p.returncode}: {p.stderr[-300:]}")
+        return pmc_conv_parse.parse(tmp, batch)
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The oracle port (torch-CPU restatement of the reference loop, pinned to the live reference in tests/test_torch_oracle.py)
     on the host cores: ResNet-50 + FDS + LDS weights + l1 + Adam at B=8 (BASELINE configs[0] batch) with an epoch tail every
@@ -409,6 +432,7 @@ def main():
                     "control flow on a one-GPU box; the throughput it prints is meaningless")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic stays null)")
     args = ap.parse_args()
 
     args.epoch_len = max(1, min(args.epoch_len, args.steps))      # at least one epoch tail inside the timed region
@@ -475,23 +499,37 @@ def main():
         ig = fam.get("conv_igemm", {"us_per_step": float("nan"), "launches_per_step": 0})
         alg_flop = 2.0 * conv_fwd_flop                                      # forward + data gradient of the 52 layers
         ach = alg_flop / (ig["us_per_step"] * 1e-6) / 1e12
-        # HBM traffic per launch: PMC counters cannot be read from inside this process; the last counter pass that was
-        # collected (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_conv_pass.py) is quoted with its source
-        traffic_note = None
-        for name in ("r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.isfile(tpath):
-                tj = json.load(open(tpath))
-                traffic_note = {"source": f"profiles/{name}", "traffic_bytes_per_launch": tj.get("traffic_bytes_per_launch"),
-                                "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_step", 0) / max(1, tj.get("launches_per_step", 1)),
-                                "launches_per_step_in_that_pass": tj.get("launches_per_step")}
-                break
+        # HBM traffic per launch: the PMC counters cannot be read from inside this process, so two separate rocprofv3 --pmc passes
+        # (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md) run as child processes over tools/pmc_conv_pass.py — every forward /
+        # data-gradient configuration of the 52 layers once, isolated — after the timed region; if rocprofv3 is not usable here,
+        # the last committed pass is quoted instead and `traffic` stays null
+        traffic, traffic_note = None, None
+        if not args.no_pmc:
+            try:
+                pm = pmc_traffic(args.batch)
+                traffic = pm["traffic_bytes_per_launch"]
+                traffic_note = {"source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over tools/pmc_conv_pass.py (isolated launches, "
+                                          "operands of the fused epilogues not included)", **{k: pm[k] for k in (
+                                              "launches_per_step", "hbm_read_bytes_per_step", "hbm_write_bytes_per_step", "algorithmic_bytes_per_step")},
+                                "algorithmic_bytes_per_launch": pm["algorithmic_bytes_per_step"] / pm["launches_per_step"]}
+                log("PMC traffic passes done")
+            except Exception as e:                                      # noqa: BLE001
+                log(f"PMC traffic passes failed ({type(e).__name__}: {e}); quoting the committed pass")
+        if traffic_note is None:
+            for name in ("r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.isfile(tpath):
+                    tj = json.load(open(tpath))
+                    traffic_note = {"source": f"profiles/{name}", "traffic_bytes_per_launch": tj.get("traffic_bytes_per_launch"),
+                                    "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_step", 0) / max(1, tj.get("launches_per_step", 1)),
+                                    "launches_per_step_in_that_pass": tj.get("launches_per_step")}
+                    break
         result["roofline"] = {
             "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_patch_kernel (hand-written MFMA implicit GEMM): every forward "
                                        "and data-gradient launch of the 52 conv layers of one training step, in situ; their store loops also carry "
                                        "the shortcut-gradient adds, ReLU masks and 43 of the 52 BatchNorm backward reductions",
             "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-            "frac_of_measured_peak": ach / peaks["bf16_mfma_TFs"], "traffic": None, "traffic_from_profiles": traffic_note,
+            "frac_of_measured_peak": ach / peaks["bf16_mfma_TFs"], "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_detail": traffic_note,
             "launches_per_step": ig["launches_per_step"], "avg_launch_us": ig["us_per_step"] / max(1.0, ig["launches_per_step"]),
             "algorithmic_flop_per_step": alg_flop, "ms_per_step_in_this_kernel": ig["us_per_step"] / 1e3,
             "method": "device time of every conv_igemm* / conv3x3_patch* launch over 4 whole training steps (profiler kernel trace), algorithmic "
