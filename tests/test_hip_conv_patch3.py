@@ -78,3 +78,22 @@ def test_patch_kernel_fused_data_gradient_epilogue():
     got = link.partial.double().sum(0)
     assert_close(got[0].cpu().numpy(), y.double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sum g")
     assert_close(got[1].cpu().numpy(), (y.double() * bnx.double()).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, msg="sum g*x")
+
+
+@pytest.mark.parametrize("c,hw", [(64, 56), (128, 28), (256, 14)])
+def test_patch_kernel_full_size_vs_per_tap(c, hw):
+    """BASELINE batch (256): every output chunk / tile of the patch-staged kernel against the per-tap kernel, and the partial
+    statistics lists of the two tilings sum to the same column sums."""
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(c * hw)
+    x = _cl(torch.randn(n, c, hw, hw, device="cuda", generator=g).to(torch.bfloat16))
+    w = _cl((torch.randn(c, c, 3, 3, device="cuda", generator=g) / np.sqrt(c * 9)).to(torch.bfloat16))
+    y3, s3 = _run(x, w, 3)
+    y1, s1 = _run(x, w, 1)
+    if c == 64:
+        assert torch.equal(y3, y1)
+    else:
+        d = (y3.float() - y1.float()).abs()
+        assert float((d > 0).float().mean()) < 0.05 and float(d.max()) <= 0.02 * float(y1.float().abs().max())
+    t3, t1 = s3.double().sum(0), s1.double().sum(0)
+    assert_close(t3.cpu().numpy(), t1.cpu().numpy(), rtol=2e-4, atol_scale=2e-4, msg="statistics")

@@ -92,3 +92,29 @@ def test_all_taps_wgrad_is_deterministic_and_ignores_poisoned_workspace():
     assert torch.equal(outs[0], outs[1])
     assert L.lib().dir_conv_wgrad3x3_workspace(n, hw, hw + 1, c, c) == 0 and L.lib().dir_conv_wgrad3x3_workspace(n, 20, 20, c, c) == 0
     assert L.lib().dir_conv_wgrad3x3_workspace(n, hw, hw, 96, c) == 0
+
+
+@pytest.mark.parametrize("c,hw", [(64, 56), (128, 28), (256, 14), (512, 7)])
+def test_all_taps_wgrad_full_size_vs_per_tap_and_linearity(c, hw):
+    """BASELINE batch (256): the two kernels agree, and the result is linear in dY (dW(a + b) = dW(a) + dW(b) up to float32 sums)."""
+    from dirhip import conv as C
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(c + hw)
+    x = _cl(torch.randn(n, c, hw, hw, device="cuda", generator=g).to(torch.bfloat16))
+    a = _cl((torch.randn(n, c, hw, hw, device="cuda", generator=g) * 0.25).to(torch.bfloat16))
+    b = _cl((torch.randn(n, c, hw, hw, device="cuda", generator=g) * 0.25).to(torch.bfloat16))
+    ab = _cl((a.float() + b.float()).to(torch.bfloat16))
+    exact = torch.equal(ab.float(), a.float() + b.float())
+    dwa, dwb, dwab = C.conv2d_wgrad(a, x, 3, 1, 1), C.conv2d_wgrad(b, x, 3, 1, 1), C.conv2d_wgrad(ab, x, 3, 1, 1)
+    prev = C.set_wgrad3_all_taps(False)
+    try:
+        dwa_tap = C.conv2d_wgrad(a, x, 3, 1, 1)
+    finally:
+        C.set_wgrad3_all_taps(prev)
+    scale = float(dwa.abs().max())
+    assert float((dwa - dwa_tap).abs().max()) <= 2e-5 * scale
+    if exact:
+        assert float((dwab - (dwa + dwb)).abs().max()) <= 2e-5 * float(dwab.abs().max())
+    else:                                                        # a + b rounded to bf16: compare against the rounded operand's own sum
+        ref = C.conv2d_wgrad(_cl((ab.float() - a.float()).to(torch.bfloat16)), x, 3, 1, 1) + dwa
+        assert float((dwab - ref).abs().max()) <= 1e-3 * float(dwab.abs().max())
