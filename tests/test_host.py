@@ -37,6 +37,39 @@ def test_cabi_argument_errors_without_gpu():
     assert L.dir_lds_weights(None, 5, 121, 1, 0, None, 0, None) == -1
 
 
+def test_conv_planning_entry_points_without_gpu():
+    """Host-side planning of the round-2 kernels (no launches): tile rows of the statistics lists, the patch-kernel switch, the
+    all-taps weight-gradient workspace and shape gate, argument checks of the new entry points."""
+    from dirhip import _lib
+    L = _lib.lib()
+    # 128-row tiles ...
+    assert L.dir_conv_tile_rows(256, 56, 56, 1, 1, 1, 0) == L.dir_conv_stats_rows(256, 56, 56) == 6272
+    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 2, 1) == L.dir_conv_stats_rows(256, 28, 28) == 1568
+    assert L.dir_conv_tile_rows(256, 7, 7, 3, 3, 1, 1) == 98                     # 7x7 maps: not a patch-kernel shape
+    # ... chunks of whole image rows for the patch-staged 3x3 / stride-1 layers (2 / 4 / 7 rows per chunk)
+    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 256 * 28
+    assert L.dir_conv_tile_rows(256, 28, 28, 3, 3, 1, 1) == 256 * 7
+    assert L.dir_conv_tile_rows(256, 14, 14, 3, 3, 1, 1) == 256 * 2
+    assert L.dir_conv_tile_rows(3, 56, 28, 3, 3, 1, 1) == L.dir_conv_stats_rows(3, 56, 28)   # not square
+    assert L.dir_conv_tile_rows(0, 56, 56, 3, 3, 1, 1) == 0
+    prev = L.dir_conv_set_patch3x3(0)
+    try:
+        assert prev == 1 and L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 6272
+    finally:
+        assert L.dir_conv_set_patch3x3(prev) == 0
+    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 256 * 28
+    # all-taps weight gradient: 256 partials of [64][9][64] floats whatever the channel count, per-tap form for other shapes
+    for c, hw in ((64, 56), (128, 28), (256, 14), (512, 7)):
+        assert L.dir_conv_wgrad3x3_workspace(256, hw, hw, c, c) == 256 * 64 * 9 * 64 * 4
+    assert L.dir_conv_wgrad3x3_workspace(1, 7, 7, 64, 64) == 1 * 64 * 9 * 64 * 4          # one chunk: one split
+    assert L.dir_conv_wgrad3x3_workspace(256, 112, 112, 64, 64) == 0 and L.dir_conv_wgrad3x3_workspace(256, 56, 56, 96, 64) == 0
+    assert L.dir_conv_wgrad3x3(None, None, None, 256, 56, 56, 64, 64, None, 0, None) == -1
+    assert L.dir_conv_dgrad_ex(None, None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 0, None, None, None, None, None, None, None) == -1
+    assert L.dir_bn_bwd_partials(None, None, None, _lib.DIR_BF16, 64, 64, None, None, None, None, None, None, 0, None, 0, None, 0, None) == -1
+    assert L.dir_augment_u8(None, None, None, _lib.DIR_F32, 1, 8, 16, None) == -1
+    assert L.dir_conv_wgrad_reduce_splits(None, 1, 4, None, None) == -1
+
+
 def test_lds_weights_native_bit_exact(golden):
     from dirhip import lds
     g = golden("lds_weights.npz")
