@@ -180,6 +180,12 @@ def measured_peaks(device):
     out["stream_read_GBs"] = nbytes / ms / 1e6
     ms = event_time_ms(lambda i: L.check(lib.dir_probe_stream_write(L.ptr(dst), nbytes, st), "write"), 10)
     out["stream_write_GBs"] = nbytes / ms / 1e6
+    # on-chip re-read rates with the latency covered (4 workgroups per CU, 8 x 16 B in flight per lane): a 2 MB region lives in
+    # every XCD's 4 MB L2, a 32 MB one only in the 256 MB Infinity Cache. The convolution K loops move ~12 TB/s from the same
+    # levels: between the two, i.e. bound by bytes in flight x latency, not by the L2's bandwidth
+    for key, region, passes in (("l2_resident_read_GBs", 2 << 20, 16), ("mall_resident_read_GBs", 32 << 20, 1)):
+        ms = event_time_ms(lambda i: L.check(lib.dir_probe_l2_read(L.ptr(src), L.ptr(red), region, 1024, passes, 8, st), key), 5)
+        out[key] = 1024 * passes * region / ms / 1e6
     del src, dst
     wgs = 256 * 8
     buf = torch.empty(wgs * 256, dtype=torch.float32, device=device)

@@ -49,6 +49,33 @@ __global__ void __launch_bounds__(DIR_TPB) probe_write_kernel(float4* __restrict
     }
 }
 
+// L2-resident re-read: every workgroup streams the same `region` bytes (a few MB: resident in each XCD's L2 after the first pass)
+// `passes` times, `DEPTH` independent 16-B loads per lane in flight -> what the L2 -> CU path delivers when latency is covered.
+template <int DEPTH>
+__global__ void __launch_bounds__(DIR_TPB) probe_l2_read_kernel(const float4* __restrict__ src, float* __restrict__ out, size_t n4, int passes) {
+    float acc = 0.0f;
+    const size_t stride = (size_t)DIR_TPB * DEPTH;
+    for (int ps = 0; ps < passes; ++ps) {
+        // each workgroup starts at its own offset so that the workgroups of a CU do not walk in lockstep
+        size_t base = ((size_t)blockIdx.x * 977 * stride + (size_t)ps * 131 * stride) % n4;
+        for (size_t done = 0; done < n4; done += stride) {
+            float4 v[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                size_t i = base + (size_t)d * DIR_TPB + threadIdx.x;
+                if (i >= n4) i -= n4;
+                v[d] = src[i];
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) acc += (v[d].x + v[d].y) + (v[d].z + v[d].w);
+            base += stride; if (base >= n4) base -= n4;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, DIR_WAVE);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
+
 template <int CHAINS>
 __global__ void __launch_bounds__(DIR_TPB) probe_mfma_bf16_kernel(int iters, float* __restrict__ out) {
     pb_f32x16 acc[CHAINS];
@@ -114,6 +141,19 @@ extern "C" int dir_probe_stream_read(const void* src, float* out /* >= 8192 floa
 extern "C" int dir_probe_stream_write(void* dst, size_t bytes, dir_stream_t stream) {
     DIR_RETURN_IF(!dst || bytes < 16384 || (bytes & 16383) || !dir_aligned16(dst), DIR_EINVAL);
     hipLaunchKernelGGL(probe_write_kernel, dim3(4096), dim3(DIR_TPB), 0, dir_s(stream), static_cast<float4*>(dst), bytes / 16, 1.0f);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// region_bytes (multiple of 16 KB, e.g. 2-8 MB) re-read `passes` times by each of `workgroups` workgroups, `depth` (4 | 8 | 16)
+// loads in flight per lane; bytes moved = workgroups * passes * region_bytes. out: >= workgroups * 4 floats.
+extern "C" int dir_probe_l2_read(const void* src, float* out, size_t region_bytes, int workgroups, int passes, int depth, dir_stream_t stream) {
+    DIR_RETURN_IF(!src || !out || region_bytes < 65536 || (region_bytes & 16383) || workgroups <= 0 || passes <= 0 || !dir_aligned16(src), DIR_EINVAL);
+    const size_t n4 = region_bytes / 16;
+    if (depth == 4) hipLaunchKernelGGL(probe_l2_read_kernel<4>, dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src), out, n4, passes);
+    else if (depth == 8) hipLaunchKernelGGL(probe_l2_read_kernel<8>, dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src), out, n4, passes);
+    else if (depth == 16) hipLaunchKernelGGL(probe_l2_read_kernel<16>, dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const float4*>(src), out, n4, passes);
+    else return DIR_EINVAL;
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

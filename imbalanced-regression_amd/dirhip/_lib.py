@@ -84,6 +84,7 @@ SIGNATURES = {
     "dir_conv_wgrad3x3_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad_reduce_splits": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
+    "dir_probe_l2_read": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "dir_probe_tr16": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dir_augment_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

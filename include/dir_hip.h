@@ -378,6 +378,10 @@ int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float*
  * no flip); out [B, S, S, 3] float32 or bf16 (dtype) = a channels_last [B, 3, S, S] tensor, float32 arithmetic exactly as
  * ToTensor / Normalize execute it ((u8 / 255 - 0.5) / 0.5; padding pixels -> -1). */
 int dir_augment_u8(const void* img, const int* params, void* out, int dtype, int B, int S, int pad, dir_stream_t stream);
+/* L2-resident re-read probe: `workgroups` workgroups each stream the same region_bytes (2-8 MB: L2 resident) `passes` times with
+ * `depth` (4 | 8 | 16) independent 16-byte loads per lane in flight: the L2 -> CU delivery rate when the latency is covered
+ * (to tell a latency-bound K loop from a bandwidth-bound one).  out: >= 4 * workgroups floats. */
+int dir_probe_l2_read(const void* src, float* out, size_t region_bytes, int workgroups, int passes, int depth, dir_stream_t stream);
 /* Test probe of the hardware-transposing LDS read the 3x3 weight gradient is built on: LDS holds the uint16 ramp 0, 1, 2, ...
  * (8192 elements); lane l of ONE wavefront issues ds_read_b64_tr_b16 at byte address addr_bytes[l] (8-byte aligned) and
  * out[4 l .. 4 l + 3] receives its four 16-bit results. */
