@@ -99,7 +99,33 @@ __device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsign
 // streams x 16 B in flight per lane while the tile is staged. Written as load-then-use inside the loop, each of them costs a
 // full memory round trip (the compiler keeps `s_waitcnt vmcnt(0)` right behind every load: found in the ISA), 8 x 3 serial
 // round trips per workgroup in the data-gradient launches.
+// Column partials of a tile's statistics: over the lanes / wavefronts that share a channel chunk, in a fixed order -> stats[mt]
 template <int BN>
+__device__ __forceinline__ void cv_epilogue_stats(const ConvP& p, float (&ssum)[8], float (&ssq)[8], float* Ss, int t, int n0, int mt) {
+    constexpr int CPR = BN / 8;
+    const int lane = t & 63, wave = t >> 6;
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = CPR; o < DIR_WAVE; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, DIR_WAVE); ssq[j] += __shfl_xor(ssq[j], o, DIR_WAVE); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * BN + lane * 8 + j] = ssum[j]; Ss[(wave * 2 + 1) * BN + lane * 8 + j] = ssq[j]; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {                                       // one thread per (which, column)
+            const int which = t / BN, col = t - which * BN;
+            const float v = (Ss[(0 * 2 + which) * BN + col] + Ss[(1 * 2 + which) * BN + col]) + (Ss[(2 * 2 + which) * BN + col] + Ss[(3 * 2 + which) * BN + col]);
+            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = v;
+        }
+    }
+}
+
+// LEAN: the launch has no fused operand (no addend / compact addend / ReLU mask / BatchNorm-backward sums, dense rows): the plain
+// forward. Those code paths then do not exist in the kernel, which brings its register count under 128 = a fourth wavefront per SIMD.
+template <int BN, bool LEAN = false, int NBATCH = 2>
 __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[(BN == 128) ? 2 : 1][2], unsigned char* smem, int t, int m0,
                                             int n0, int mt) {
     constexpr int MI = (BN == 128) ? 2 : 1;
@@ -121,6 +147,29 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     const size_t go0 = (size_t)(m0 + srow) * p.Cout + n0 + sch * 8;
     const size_t gstep = (size_t)RPI * p.Cout;
     const bool full = m0 + CV_BM <= p.M;
+    if constexpr (LEAN) {
+        __syncthreads();
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (full || m0 + srow + i * RPI < p.M) {
+                const uint4 c = *reinterpret_cast<const uint4*>(cs + i * RPI * CS_STRIDE);
+                if (p.stats) {
+                    const uint32_t sw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const float f0 = __uint_as_float(sw[q2] << 16), f1 = __uint_as_float(sw[q2] & 0xffff0000u);
+                        ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
+                    }
+                }
+                *reinterpret_cast<uint4*>(p.y + go0 + (size_t)i * gstep) = c;
+            }
+        }
+        cv_epilogue_stats<BN>(p, ssum, ssq, Ss, t, n0, mt);
+        return;
+    }
     const bool fwd_stats = p.stats && !p.bnx;
     const bool decode = p.o2 || p.addend2;                      // rows need their (n, ho, wo)
 
@@ -143,9 +192,9 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
 
     // The thread's rows in two halves: (operand loads of a half, all in flight together) -> (its arithmetic and stores). The first
     // half's loads are issued before the barrier that publishes the staging tile. (All rows at once would need 100+ registers.)
-    constexpr int HALF = NIT / 2;
+    constexpr int HALF = NIT / NBATCH;                          // rows per batch (NBATCH = 4: fewer registers, for the 4-per-CU variant)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < NBATCH; ++hh) {
         uint32_t orow[HALF];                                    // element offset of the row's chunk in y (and in bnx / addend / mask)
         uint32_t o2row[HALF];                                   // ... of its compact stride-2 addend, or ~0u
         uint4 v_add[HALF], v_mask[HALF], v_bnx[HALF];
@@ -245,31 +294,15 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
             }
         }
     }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = CPR; o < DIR_WAVE; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, DIR_WAVE); ssq[j] += __shfl_xor(ssq[j], o, DIR_WAVE); }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * BN + lane * 8 + j] = ssum[j]; Ss[(wave * 2 + 1) * BN + lane * 8 + j] = ssq[j]; }
-        }
-        __syncthreads();
-        if (t < 2 * BN) {                                       // one thread per (which, column)
-            const int which = t / BN, col = t - which * BN;
-            const float v = (Ss[(0 * 2 + which) * BN + col] + Ss[(1 * 2 + which) * BN + col]) + (Ss[(2 * 2 + which) * BN + col] + Ss[(3 * 2 + which) * BN + col]);
-            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = v;
-        }
-    }
+    cv_epilogue_stats<BN>(p, ssum, ssq, Ss, t, n0, mt);
 }
 
 // PF = prefetch distance of the global loads in K-steps. The K loop is bound by load latency, not by MFMA or LDS
 // throughput: a 32 KB K-tile takes > 1 us to arrive under load while its 16 MFMAs per wavefront take 0.2 us, so the
 // rate is (bytes in flight per CU) / latency. PF = 2 keeps two K-tiles per workgroup in flight in two register sets
 // (p, q) for 32 more VGPRs (2 instead of 3 wavefronts per SIMD, which the 64 KB two-stage LDS image allows anyway).
-template <int BN, int PF, int NBUF>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu((PF == 2 || (NBUF == 2 && BN == 128)) ? 2 : 3)))   // (two 32 KB stages: LDS admits 2 workgroups per CU anyway)
+template <int BN, int PF, int NBUF, bool LEAN = false>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu((PF == 2 || (NBUF == 2 && BN == 128)) ? 2 : (LEAN && NBUF == 1 ? 4 : 3))))   // (two 32 KB stages: LDS admits 2 workgroups per CU anyway)
 conv_igemm_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
@@ -334,21 +367,21 @@ conv_igemm_kernel(ConvP p) {
     // row lrow + 32 i equals that of lrow) and one per fragment read of a K-step
     uint32_t st_off = lrow * CV_ROWB + ((lchunk ^ ((lrow >> 1) & 7)) << 4);
     asm volatile("" : "+v"(st_off));
-    uint32_t af[MI][4], bf[NI][4];
+    // fragment read offsets: row * 128 + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4) = base ^ (kk << 5) with ONE base per 32-row
+    // fragment (kk * 2 and fhalf occupy different bits, and the XOR part stays below the 128-byte row pitch): 4 registers
+    // instead of 16, one v_xor per read
+    uint32_t afb[MI], bfb[NI];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * WM + mi * 32 + frow;
+        afb[mi] = row * CV_ROWB + ((fhalf ^ ((row >> 1) & 7)) << 4);
+        asm volatile("" : "+v"(afb[mi]));
+    }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row = wm * WM + mi * 32 + frow;
-            af[mi][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
-            asm volatile("" : "+v"(af[mi][kk]));
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int row = wn * 64 + ni * 32 + frow;
-            bf[ni][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
-            asm volatile("" : "+v"(bf[ni][kk]));
-        }
+    for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * 64 + ni * 32 + frow;
+        bfb[ni] = row * CV_ROWB + ((fhalf ^ ((row >> 1) & 7)) << 4);
+        asm volatile("" : "+v"(bfb[ni]));
     }
 
     // K-step cursor (wave-uniform): filter tap and 64-channel block of the NEXT tile to fetch, and its index
@@ -399,9 +432,9 @@ conv_igemm_kernel(ConvP p) {
         for (int kk = 0; kk < 4; ++kk) {                                                                        \
             bf16x8 a[MI], b[NI];                                                                                \
             _Pragma("unroll")                                                                                   \
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + af[mi][kk]); \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(As + (buf) * A_BYTES + (afb[mi] ^ (kk << 5))); \
             _Pragma("unroll")                                                                                   \
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + bf[ni][kk]); \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bs + (buf) * B_BYTES + (bfb[ni] ^ (kk << 5))); \
             _Pragma("unroll")                                                                                   \
             for (int mi = 0; mi < MI; ++mi)                                                                     \
                 _Pragma("unroll")                                                                               \
@@ -472,7 +505,7 @@ conv_igemm_kernel(ConvP p) {
 #undef CV_ST
 #undef CV_BL
 
-    cv_epilogue<BN>(p, acc, smem, t, m0, n0, mt);
+    cv_epilogue<BN, LEAN>(p, acc, smem, t, m0, n0, mt);
 }
 
 
@@ -493,8 +526,11 @@ __device__ __forceinline__ void cv_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voffset, soffset, 0, 0);
 }
 
-template <int BN>
-__global__ void __launch_bounds__(DIR_TPB)
+// NST = LDS stages: 2 = tile kt+1 in flight while tile kt is multiplied (long K loops); 1 = one 32 KB stage, so that with the LEAN
+// epilogue (no fused operand) a workgroup needs < 40 KB of LDS and <= 128 registers: FOUR workgroups per CU for the short-K forward
+// launches, whose throughput follows the number of resident workgroups (profiles/r02_conv_occupancy_sensitivity.txt).
+template <int BN, int NST = 2, bool LEAN = false>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(NST == 1 ? 4 : 2)))
 conv_igemm_dma_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = CV_BM * CV_ROWB;              // 16 KB
@@ -613,28 +649,37 @@ conv_igemm_dma_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
+    if (NST == 1) {
+        for (int kt = 0; kt < p.KT; ++kt) {
+            CV_ISSUE_TILE(0);
+            __syncthreads();                                        // (drains the DMA: vmcnt(0) before the barrier)
+            CV_MFMA_STEP(0);
+            __syncthreads();
+        }
+    } else {
     CV_ISSUE_TILE(0);
-    __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
-    // Two K-steps per trip (stages 0 and 1 are literals), whole pairs only and the odd last step peeled off AFTER the loop:
-    // a `break` between the two halves gives the loop two exits and makes the compiler carry a second copy of the 64
-    // accumulators through v_accvgpr_read / v_accvgpr_write (138 extra VALU per 32 MFMAs, each waiting for its MFMA).
-    int kt = 0;
-    for (; kt + 2 <= p.KT; kt += 2) {
-        CV_ISSUE_TILE(1);                                       // tile kt + 1
-        CV_MFMA_STEP(0);                                        // tile kt
-        __syncthreads();
-        if (kt + 2 < p.KT) CV_ISSUE_TILE(0);                    // tile kt + 2
-        CV_MFMA_STEP(1);                                        // tile kt + 1
-        __syncthreads();
-    }
-    if (kt < p.KT) {                                            // odd K-step count: the last tile sits in stage 0
-        CV_MFMA_STEP(0);
-        __syncthreads();
+        __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
+        // Two K-steps per trip (stages 0 and 1 are literals), whole pairs only and the odd last step peeled off AFTER the loop:
+        // a `break` between the two halves gives the loop two exits and makes the compiler carry a second copy of the 64
+        // accumulators through v_accvgpr_read / v_accvgpr_write (138 extra VALU per 32 MFMAs, each waiting for its MFMA).
+        int kt = 0;
+        for (; kt + 2 <= p.KT; kt += 2) {
+            CV_ISSUE_TILE(1);                                       // tile kt + 1
+            CV_MFMA_STEP(0);                                        // tile kt
+            __syncthreads();
+            if (kt + 2 < p.KT) CV_ISSUE_TILE(0);                    // tile kt + 2
+            CV_MFMA_STEP(1);                                        // tile kt + 1
+            __syncthreads();
+        }
+        if (kt < p.KT) {                                            // odd K-step count: the last tile sits in stage 0
+            CV_MFMA_STEP(0);
+            __syncthreads();
+        }
     }
 #undef CV_MFMA_STEP
 #undef CV_ISSUE_TILE
 #undef CV_DMA
-    cv_epilogue<BN>(p, acc, smem, t, m0, n0, mt);
+    cv_epilogue<BN, LEAN, (NST == 1 && !LEAN) ? 4 : 2>(p, acc, smem, t, m0, n0, mt);
 }
 
 
@@ -1054,8 +1099,18 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
     (void)once;
 #define CV_LAUNCH(BN_, PF_, NB_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, PF_, NB_>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p)
-    if (wide) { if (pf == 2) CV_LAUNCH(128, 2, 2); else if (p.nbuf == 2) CV_LAUNCH(128, 1, 2); else CV_LAUNCH(128, 1, 1); }
-    else      { if (pf == 2) CV_LAUNCH(64, 2, 2);  else if (p.nbuf == 2) CV_LAUNCH(64, 1, 2);  else CV_LAUNCH(64, 1, 1); }
+    // lean = no fused operand (the plain forward): the single-stage kernel then fits four workgroups per CU
+    const bool lean = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
+    // 128-wide tiles, short K loops (<= 18 steps): the single-stage LDS-DMA kernel, FOUR workgroups per CU (114 registers, 39 KB
+    // of LDS) instead of three — throughput of these launches follows the resident workgroups (profiles/r02_conv_occupancy_sensitivity.txt;
+    // A/B per train step -0.8 ms, per epoch-tail forward -0.7 ms). The 64-wide register-staged kernel already runs four per CU
+    // (the DMA form measured slower there).
+    const bool single = wide && p.nbuf == 1 && pf == 1 && variant == 0;
+    if (single && lean) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 1, true>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
+    else if (single) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 1, false>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
+    else if (!wide && lean && p.nbuf == 1 && pf == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, 1, 1, true>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
+    else if (wide) { if (pf == 2) CV_LAUNCH(128, 2, 2); else if (p.nbuf == 2) CV_LAUNCH(128, 1, 2); else CV_LAUNCH(128, 1, 1); }
+    else           { if (pf == 2) CV_LAUNCH(64, 2, 2);  else if (p.nbuf == 2) CV_LAUNCH(64, 1, 2);  else CV_LAUNCH(64, 1, 1); }
 #undef CV_LAUNCH
     DIR_LAUNCH_CHECK();
     return DIR_OK;
