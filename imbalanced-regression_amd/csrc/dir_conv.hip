@@ -720,8 +720,10 @@ __device__ __forceinline__ void cp_dma16(cp_u32x4 rs, uint32_t lds_addr, int vof
 }
 __device__ __forceinline__ void cp_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int WI, int BN>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(2)))
+// NST = 2: two patch stages (Cin > 64) and two weight stages, the next slice in flight under the MFMAs: 56-80 KB of LDS, two
+// workgroups per CU. NST = 1: one stage each (<= 40 KB, <= 128 registers): FOUR workgroups per CU, no overlap inside a workgroup.
+template <int WI, int BN, int NST>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(NST == 1 ? 4 : 2)))
 conv3x3_patch_kernel(ConvP p) {
     using G = CpGeom<WI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -731,7 +733,7 @@ conv3x3_patch_kernel(ConvP p) {
     constexpr int NI = 2;
     constexpr int WM = MI * 32;
     // LDS: [patch stage 0][patch stage 1 (only used when Cin > 64)][B stage 0][B stage 1]
-    const int npatch = p.cpk > 1 ? 2 : 1;
+    const int npatch = (NST == 2 && p.cpk > 1) ? 2 : 1;
     const uint32_t b_base = (uint32_t)(npatch * G::PATCH);
     int lin;
     {
@@ -845,23 +847,37 @@ conv3x3_patch_kernel(ConvP p) {
         }                                                                                                       \
     }
 
-    CP_ISSUE_PATCH(0, 0);
-    CP_ISSUE_B(0, 0, 0);
-    cp_dma_wait();
-    __syncthreads();
-    int bs = 0;
-    for (int cb = 0; cb < p.cpk; ++cb) {
-        const int ps = cb & 1;
-        if (cb + 1 < p.cpk) CP_ISSUE_PATCH(cb + 1, ps ^ 1);       // next channel block's patch lands during this block's nine taps
+    if (NST == 1) {
+        for (int cb = 0; cb < p.cpk; ++cb) {
+            CP_ISSUE_PATCH(cb, 0);                                  // (everyone is past the previous block's last MFMA: barrier below)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // next weight slice in flight during the MFMAs (the first slice of the next channel block after tap 8)
-            if (tap < 8) { CP_ISSUE_B(tap + 1, cb, bs ^ 1); }
-            else if (cb + 1 < p.cpk) { CP_ISSUE_B(0, cb + 1, bs ^ 1); }
-            CP_MFMA_STEP(tap / 3, tap % 3, ps, bs);
-            cp_dma_wait();
-            __syncthreads();
-            bs ^= 1;
+            for (int tap = 0; tap < 9; ++tap) {
+                CP_ISSUE_B(tap, cb, 0);
+                cp_dma_wait();
+                __syncthreads();
+                CP_MFMA_STEP(tap / 3, tap % 3, 0, 0);
+                __syncthreads();
+            }
+        }
+    } else {
+    CP_ISSUE_PATCH(0, 0);
+        CP_ISSUE_B(0, 0, 0);
+        cp_dma_wait();
+        __syncthreads();
+        int bs = 0;
+        for (int cb = 0; cb < p.cpk; ++cb) {
+            const int ps = cb & 1;
+            if (cb + 1 < p.cpk) CP_ISSUE_PATCH(cb + 1, ps ^ 1);       // next channel block's patch lands during this block's nine taps
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // next weight slice in flight during the MFMAs (the first slice of the next channel block after tap 8)
+                if (tap < 8) { CP_ISSUE_B(tap + 1, cb, bs ^ 1); }
+                else if (cb + 1 < p.cpk) { CP_ISSUE_B(0, cb + 1, bs ^ 1); }
+                CP_MFMA_STEP(tap / 3, tap % 3, ps, bs);
+                cp_dma_wait();
+                __syncthreads();
+                bs ^= 1;
+            }
         }
     }
 #undef CP_MFMA_STEP
@@ -869,7 +885,7 @@ conv3x3_patch_kernel(ConvP p) {
 #undef CP_ISSUE_PATCH
     ConvP pe = p;
     pe.M = m0 + G::KPIX;                                          // rows past the chunk's pixels are padding: not stored, not counted
-    cv_epilogue<BN>(pe, acc, smem, t, m0, n0, mt);
+    cv_epilogue<BN, false, NST == 1 ? 4 : 2>(pe, acc, smem, t, m0, n0, mt);
 }
 
 template <int WI> constexpr int cp_chunks_per_image() { return CpGeom<WI>::CPI; }
@@ -887,10 +903,11 @@ static int cp_width(int H, int W, int R, int S, int stride, int pad) {
     return (g_patch3x3_on() && R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)) ? W : 0;
 }
 static int cp_chunks(int W) { return W == 56 ? 28 : W == 28 ? 7 : 2; }
-// A/B switch for tools and tests (process-wide, default on): off = those layers take the per-tap kernels again. Returns the
+// A/B switch for tools and tests (process-wide, default 1): 0 = those layers take the per-tap kernels again, 1 = patch-staged,
+// single LDS stage (four workgroups per CU), 2 = patch-staged, two stages (two per CU; measured 0.16 ms per step slower). Returns the
 // previous setting. Changes dir_conv_tile_rows accordingly — flip it only between whole forward/backward passes.
 static int g_patch3x3 = 1;
-extern "C" int dir_conv_set_patch3x3(int enabled) { const int prev = g_patch3x3; g_patch3x3 = enabled ? 1 : 0; return prev; }
+extern "C" int dir_conv_set_patch3x3(int mode) { const int prev = g_patch3x3; g_patch3x3 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return prev; }
 static int g_patch3x3_on() { return g_patch3x3; }
 
 // Rows of the per-tile statistics / BatchNorm-partial list of ONE launch with this geometry (the tiling depends on the kernel
@@ -1060,16 +1077,18 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     if (cpw) {
         // patch-staged 3x3: M tiles = chunks of whole image rows
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
-        const int npatch = p.cpk > 1 ? 2 : 1;
+        const int nst = g_patch3x3 == 2 ? 2 : 1;                        // default: single stage, four workgroups per CU
+        const int npatch = (nst == 2 && p.cpk > 1) ? 2 : 1;
         const int prows = cpw == 56 ? 256 : cpw == 28 ? 192 : 144;
-        const int loop3 = npatch * prows * CV_ROWB + 2 * tile_n * CV_ROWB;
+        const int loop3 = npatch * prows * CV_ROWB + nst * tile_n * CV_ROWB;
         const int lds3 = loop3 > stage ? loop3 : stage;
 #define CP_LAUNCH(W_, BN_)                                                                                                    \
         {                                                                                                                         \
-            static bool once_cp = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<W_, BN_>),         \
+            static bool once_cp = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<W_, BN_, 2>),      \
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);            \
             (void)once_cp;                                                                                                        \
-            hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);                       \
+            if (nst == 1) hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_, 1>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);      \
+            else hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_, 2>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);               \
         }
         if (cpw == 56) { if (wide) CP_LAUNCH(56, 128) else CP_LAUNCH(56, 64) }
         else if (cpw == 28) { if (wide) CP_LAUNCH(28, 128) else CP_LAUNCH(28, 64) }

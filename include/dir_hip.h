@@ -266,8 +266,9 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
  * instead of nine shifted fetches of the same pixels).  Use this to size `stats` of dir_conv_fwd* / dir_conv_dgrad_bnstats. */
 size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
 /* A/B switch for tools and tests (process-wide, default 1): 0 = the 3x3 / stride-1 layers take the per-tap kernels again (and
- * dir_conv_tile_rows answers accordingly).  Returns the previous setting; flip only between whole passes. */
-int dir_conv_set_patch3x3(int enabled);
+ * dir_conv_tile_rows answers accordingly), 1 = patch-staged with one LDS stage (four workgroups per CU), 2 = patch-staged with
+ * two stages (two per CU).  Returns the previous setting; flip only between whole passes. */
+int dir_conv_set_patch3x3(int mode);
 /* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
