@@ -476,7 +476,7 @@ int prepare_impl(const void* x_, int64_t M, int C, const float* gamma, const flo
     int splits = prow / 64;                                        // >= 64 rows per fold workgroup
     if (splits > 32) splits = 32;
     if (splits > g.rblocks / 2) splits = g.rblocks / 2;            // folded doubles live in the (unused) partial area
-    if (ext_partial && splits >= 4) {
+    if (ext_partial && splits >= 16) {      // (lists under 1024 rows: one finalize launch reads them directly, 32 rows per trip)
         const int rps = dir_cdiv(prow, splits);
         splits = dir_cdiv(prow, rps);
         double* folded = reinterpret_cast<double*>(w.partial);
@@ -549,7 +549,7 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
         int splits = ext_rows / 64;
         if (splits > 32) splits = 32;
         if (splits > g.rblocks / 2) splits = g.rblocks / 2;
-        if (splits >= 4) {
+        if (splits >= 16) {
             const int rps = dir_cdiv(ext_rows, splits);
             splits = dir_cdiv(ext_rows, rps);
             double* folded = reinterpret_cast<double*>(w.partial);
