@@ -6,7 +6,12 @@ convolutions in float64. They pin the formulas (not the kernels — those are co
   * the decomposition of a 3x3 / stride-2 / pad-1 data gradient into four stride-1 convolutions by output-pixel parity,
     with the class-packed weight layout of conv_prep_rot_index (csrc/dir_conv.hip), against autograd;
   * the compact stride-2 1x1 gradient added at the even pixels (dir_conv_dgrad_join) against autograd;
-  * the 24-element row windows and packed weights of the stem kernels (csrc/dir_stem.hip), forward and weight gradient.
+  * the 24-element row windows and packed weights of the stem kernels (csrc/dir_stem.hip), forward and weight gradient;
+  * the LDS image of the all-taps 3x3 weight gradient (csrc/dir_conv_wgrad3.hip): DMA piece -> (row, physical chunk) with the
+    half-swap swizzle on the SOURCE side, the transposing-read lane mapping (as pinned on the GPU by dir_probe_tr16), the per-lane
+    patch slot of a pixel, taps as row offsets, operand k order and the C/D layout — an emulated workgroup reproduces dW;
+  * the patch-staged 3x3 kernel's addressing (csrc/dir_conv.hip, conv3x3_patch_kernel): the tap row is an immediate under the
+    XOR swizzle because the row pitch is a multiple of 16 rows; fragment address = base ^ (kk << 5).
 """
 import numpy as np
 import pytest
@@ -191,3 +196,112 @@ def test_float_reciprocal_division_is_exact_below_2_to_24(d):
         m = m[(m >= 0) & (m < (1 << 24))]
         q, r = decode(m)
         assert np.array_equal(q, m // d) and np.array_equal(r, m % d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# All-taps 3x3 weight gradient (csrc/dir_conv_wgrad3.hip), restated lane by lane for one workgroup and one chunk
+W3_GEOM = {56: dict(RB=2, P=60), 28: dict(RB=4, P=32), 14: dict(RB=7, P=16), 7: dict(RB=7, P=12)}
+
+
+def _tr_read(lds, addr):
+    """ds_read_b64_tr_b16 of one wavefront: addr[64] byte addresses -> [64][4] 16-bit values. Within each 16-lane group lane i
+    supplies the address of row (i >> 2), columns 4 (i & 3) .. + 3 and receives column i, rows 0 .. 3."""
+    out = np.zeros((64, 4), dtype=lds.dtype)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for j in range(4):
+            src = 16 * g + 4 * j + (i >> 2)
+            out[l, j] = lds[addr[src] // 2 + (i & 3)]
+    return out
+
+
+@pytest.mark.parametrize("wi", [56, 28, 14, 7])
+def test_all_taps_wgrad_lds_image_and_transposing_reads(wi):
+    g = W3_GEOM[wi]
+    RB, P, H = g["RB"], g["P"], wi
+    KPIX = RB * wi
+    NK = (KPIX + 15) // 16
+    DY_PIECES = NK * 2
+    XP = (RB + 2) * P
+    X_PIECES = (XP + 7) // 8
+    PIECES = DY_PIECES + X_PIECES
+    DY_BYTES = DY_PIECES * 1024
+    rng = np.random.default_rng(wi)
+    C = 64
+    n_img = 2
+    # small integers: every product and sum below is exact in float32, so the emulation can be compared with == 
+    x = rng.integers(-3, 4, (n_img, H, wi, C)).astype(np.float32)
+    dy = rng.integers(-3, 4, (n_img, H, wi, C)).astype(np.float32)
+    acc = np.zeros((9, 64, 64), np.float64)                                  # [tap][co][ci] for the (co block 0, ci block 0) workgroup
+    for n in range(n_img):
+        for h0 in range(0, H, RB):
+            lds = np.zeros(PIECES * 512, np.float32)                         # one stage as 16-bit elements (values stored as floats)
+            # ---- DMA: piece q, lane -> LDS element q*512 + lane*8 .. + 7; source chunk swizzled on bit 1 of the row
+            for q in range(PIECES):
+                for lane in range(64):
+                    lrow, pc8 = lane >> 3, lane & 7
+                    lchunk = pc8 ^ (((lane >> 4) & 1) << 2)
+                    vals = np.zeros(8, np.float32)
+                    if q < DY_PIECES:
+                        k = q * 8 + lrow
+                        if k < KPIX:
+                            vals = dy[n, h0 + k // wi, k % wi, lchunk * 8:lchunk * 8 + 8]
+                    else:
+                        slot = (q - DY_PIECES) * 8 + lrow
+                        pr, pc = slot // P, slot % P
+                        hi = h0 - 1 + pr
+                        if slot < XP and 1 <= pc <= wi and 0 <= hi < H:
+                            vals = x[n, hi, pc - 1, lchunk * 8:lchunk * 8 + 8]
+                    lds[q * 512 + lane * 8:q * 512 + lane * 8 + 8] = vals
+            # ---- every wavefront (co half wm, ci half wn, 16-pixel steps of parity kpar)
+            for wave in range(8):
+                kpar, wm, wn = wave >> 2, (wave >> 1) & 1, wave & 1
+                lane = np.arange(64)
+                hf, r4 = lane >> 5, (lane >> 2) & 3
+                lane_c = ((lane >> 4) & 1) * 32 + (lane & 3) * 8
+                dyl = (8 * hf + r4) * 128 + ((wm ^ (r4 >> 1)) << 6) + lane_c + kpar * 2048
+                xl = DY_BYTES + lane_c
+                for tk in range((NK + 1) // 2):
+                    kk = kpar + 2 * tk
+                    if kk >= NK:
+                        continue
+                    a = np.concatenate([_tr_read(lds, dyl + tk * 4096), _tr_read(lds, dyl + tk * 4096 + 512)], 1)   # [lane][8 k]
+                    pp0 = []
+                    for j in range(2):
+                        k = 16 * kk + 8 * hf + 4 * j + r4
+                        pp0.append(np.where(k < KPIX, (k // wi) * P + k % wi, 0))
+                    for s_ in range(3):
+                        q0, q1 = pp0[0] + s_, pp0[1] + s_
+                        x0 = xl + (q0 << 7) + ((((q0 >> 1) & 1) ^ wn) << 6)
+                        x1 = xl + (q1 << 7) + ((((q1 >> 1) & 1) ^ wn) << 6)
+                        for r_ in range(3):
+                            b = np.concatenate([_tr_read(lds, x0 + r_ * P * 128), _tr_read(lds, x1 + r_ * P * 128)], 1)
+                            # v_mfma_f32_32x32x16: lane l supplies row / column (l & 31), k = 8 (l >> 5) + e
+                            A = np.zeros((32, 16)); B = np.zeros((32, 16))
+                            for l in range(64):
+                                A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a[l]
+                                B[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = b[l]
+                            acc[r_ * 3 + s_, wm * 32:wm * 32 + 32, wn * 32:wn * 32 + 32] += A @ B.T
+    ref = torch.nn.grad.conv2d_weight(torch.as_tensor(x).permute(0, 3, 1, 2).double(), (C, C, 3, 3),
+                                      torch.as_tensor(dy).permute(0, 3, 1, 2).double(), padding=1).numpy()      # [co][ci][r][s]
+    got = acc.reshape(3, 3, 64, 64).transpose(2, 3, 0, 1)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("wi,P", [(56, 64), (28, 32), (14, 16)])
+def test_patch_kernel_tap_rows_are_immediates_under_the_swizzle(wi, P):
+    """conv3x3_patch_kernel: physical 16-B chunk of logical chunk c in patch row pp is c ^ ((pp >> 1) & 7). A tap (r, s) reads row
+    pp0 + s + r * P: with P a multiple of 16 the swizzle term depends on pp0 + s only, so r * P * 128 is an address immediate; and
+    row * 128 + (((kk * 2 + fhalf) ^ z) << 4) == (row * 128 + ((fhalf ^ z) << 4)) ^ (kk << 5) — one base register per fragment."""
+    assert P % 16 == 0 and P >= wi + 2
+    for pp0 in range(0, 4 * P):
+        for s_ in range(3):
+            z = ((pp0 + s_) >> 1) & 7
+            for r_ in range(3):
+                assert (((pp0 + s_ + r_ * P) >> 1) & 7) == z
+    for row in range(256):
+        z = (row >> 1) & 7
+        for fhalf in range(2):
+            base = row * 128 + ((fhalf ^ z) << 4)
+            for kk in range(4):
+                assert row * 128 + (((kk * 2 + fhalf) ^ z) << 4) == base ^ (kk << 5)
