@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t cv_f2bf(float f) {
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t cv_u32x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // two floats -> packed bf16x2 (round to nearest even, quiet NaN): one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t cv_pack_bf16(float lo, float hi) {
@@ -175,24 +176,119 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
 
     // fused BatchNorm-backward partials: (sum g, sum g * bnx) of the gradient as stored, optionally under the recomputed ReLU mask
     float maf[8], mbf[8];
-    if (p.bnx && p.bn_gamma) {
+    auto mask_coefficients = [&]() {
+        if (p.bnx && p.bn_gamma) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                           // same expression as dir_bn.hip's bn_mask_coef (= the forward's coefficients)
-            const int ch = n0 + sch * 8 + j;
-            const double gm = (double)p.bn_gamma[ch], rs = (double)p.bn_rstd[ch];
-            maf[j] = (float)(gm * rs);
-            mbf[j] = (float)((double)p.bn_beta[ch] - (double)p.bn_mean[ch] * gm * rs);
+            for (int j = 0; j < 8; ++j) {                       // same expression as dir_bn.hip's bn_mask_coef (= the forward's coefficients)
+                const int ch = n0 + sch * 8 + j;
+                const double gm = (double)p.bn_gamma[ch], rs = (double)p.bn_rstd[ch];
+                maf[j] = (float)(gm * rs);
+                mbf[j] = (float)((double)p.bn_beta[ch] - (double)p.bn_mean[ch] * gm * rs);
+            }
         }
-    }
+    };
     // BatchNorm statistics of the ROUNDED outputs (what the following BatchNorm reads): this thread's 8 channels over the rows
     // it stores, then over the lanes / wavefronts that share the channel chunk, in a fixed order
     float ssum[8], ssq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
 
-    // The thread's rows in two halves: (operand loads of a half, all in flight together) -> (its arithmetic and stores). The first
-    // half's loads are issued before the barrier that publishes the staging tile. (All rows at once would need 100+ registers.)
     constexpr int HALF = NIT / NBATCH;                          // rows per batch (NBATCH = 4: fewer registers, for the 4-per-CU variant)
+    // Dense rows (every stride-1 launch): the thread's rows in batches, software-pipelined — batch b + 1's operand loads are issued
+    // BEFORE batch b's arithmetic and stores — and free of control flow around the memory instructions: loads and stores are buffer
+    // instructions, the descriptor of an operand the launch does not have is EMPTY (out-of-range lanes read zeros / store nothing,
+    // without a memory access) and the descriptors end at row M, which also drops the rows of a ragged tile. The wait counter is
+    // in issue order, so the compiler can then wait for "everything but the newest N" and N covers the stores: nothing in the
+    // epilogue waits for a store to be acknowledged. With a conditional store or load in between it has to assume the shortest
+    // path and emits `s_waitcnt vmcnt(0)` — in the general loop below that is one store round trip per row, eight in a row per
+    // workgroup tile (found in the ISA; same-box A/B of the full-tile form: -0.13 ms per train step).
+    if (!decode) {
+        const uint32_t ybytes = (uint32_t)p.M * (uint32_t)p.Cout * 2u;
+        const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, (int)ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.addend), (short)0, p.addend ? (int)ybytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.mask), (short)0, p.mask ? (int)ybytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_bnx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bnx), (short)0, p.bnx ? (int)ybytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask_bits), (short)0, p.mask_bits ? (int)(ybytes >> 4) : 0, 0x00020000);
+        const uint32_t gob = (uint32_t)go0 * 2u, gsb = (uint32_t)gstep * 2u;     // byte offsets of the thread's first row chunk / row step
+        cv_u32x4 f_add[2][HALF], f_mask[2][HALF], f_bnx[2][HALF];
+        uint32_t f_bits[2][HALF];
+#define CV_EPI_LOAD(set, hh_)                                                                                   \
+        _Pragma("unroll")                                                                                       \
+        for (int ii = 0; ii < HALF; ++ii) {                                                                     \
+            const uint32_t ob = gob + (uint32_t)((hh_) * HALF + ii) * gsb;                                      \
+            f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)ob, 0, 0);                       \
+            f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 0);                     \
+            f_bits[set][ii] = __builtin_amdgcn_raw_buffer_load_b8(r_bits, (int)(ob >> 4), 0, 0);                \
+            f_bnx[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_bnx, (int)ob, 0, 0);                       \
+        }
+        CV_EPI_LOAD(0, 0);
+        mask_coefficients();                                    // (its loads travel together with the first batch's)
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < NBATCH; ++hh) {
+            const int set = hh & 1;
+            if (hh + 1 < NBATCH) { CV_EPI_LOAD(set ^ 1, hh + 1); }
+#pragma unroll
+            for (int ii = 0; ii < HALF; ++ii) {
+                const int i = hh * HALF + ii;
+                const cv_u32x4 cc = *reinterpret_cast<const cv_u32x4*>(cs + i * RPI * CS_STRIDE);
+                uint32_t cw[4] = {cc.x, cc.y, cc.z, cc.w};
+                if (!full && !(m0 + srow + i * RPI < p.M)) cw[0] = cw[1] = cw[2] = cw[3] = 0u;   // (not stored; zeros in the sums)
+                if (fwd_stats) {
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const float f0 = __uint_as_float(cw[q2] << 16), f1 = __uint_as_float(cw[q2] & 0xffff0000u);
+                        ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
+                    }
+                }
+                if (p.addend) {                                 // y = bf16(bf16(conv) + addend), like an eager add kernel
+                    const uint32_t aw[4] = {f_add[set][ii].x, f_add[set][ii].y, f_add[set][ii].z, f_add[set][ii].w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2)
+                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                }
+                if (p.mask) {                                   // ReLU backward of the tensor this gradient belongs to
+                    const uint32_t kw[4] = {f_mask[set][ii].x, f_mask[set][ii].y, f_mask[set][ii].z, f_mask[set][ii].w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        if (!(__uint_as_float(kw[q2] << 16) > 0.0f)) cw[q2] &= 0xffff0000u;
+                        if (!(__uint_as_float(kw[q2] & 0xffff0000u) > 0.0f)) cw[q2] &= 0x0000ffffu;
+                    }
+                }
+                if (p.mask_bits) {                              // the same decision, from the forward's bit per element
+                    const uint32_t bb = f_bits[set][ii];
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        if (!(bb & (1u << (2 * q2)))) cw[q2] &= 0xffff0000u;
+                        if (!(bb & (2u << (2 * q2)))) cw[q2] &= 0x0000ffffu;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{cw[0], cw[1], cw[2], cw[3]}, r_y, (int)(gob + (uint32_t)i * gsb), 0, 0);
+                if (p.bnx) {
+                    const uint32_t xw[4] = {f_bnx[set][ii].x, f_bnx[set][ii].y, f_bnx[set][ii].z, f_bnx[set][ii].w};
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        float g0 = __uint_as_float(cw[q2] << 16), g1 = __uint_as_float(cw[q2] & 0xffff0000u);
+                        const float x0 = __uint_as_float(xw[q2] << 16), x1 = __uint_as_float(xw[q2] & 0xffff0000u);
+                        if (p.bn_gamma) {
+                            if (!(x0 * maf[2 * q2] + mbf[2 * q2] > 0.0f)) g0 = 0.0f;
+                            if (!(x1 * maf[2 * q2 + 1] + mbf[2 * q2 + 1] > 0.0f)) g1 = 0.0f;
+                        }
+                        ssum[2 * q2] += g0; ssq[2 * q2] += g0 * x0; ssum[2 * q2 + 1] += g1; ssq[2 * q2 + 1] += g1 * x1;
+                    }
+                }
+            }
+        }
+#undef CV_EPI_LOAD
+        cv_epilogue_stats<BN>(p, ssum, ssq, Ss, t, n0, mt);
+        return;
+    }
+
+    mask_coefficients();
+    // The general loop (scattered rows of the stride-2 classes, compact stride-2 addend): the thread's rows in
+    // batches, (operand loads of a batch, all in flight together) -> (its arithmetic and stores). The first batch's loads are issued
+    // before the barrier that publishes the staging tile. (All rows at once would need 100+ registers.)
 #pragma unroll
     for (int hh = 0; hh < NBATCH; ++hh) {
         uint32_t orow[HALF];                                    // element offset of the row's chunk in y (and in bnx / addend / mask)
