@@ -165,7 +165,9 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                         ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
                     }
                 }
-                *reinterpret_cast<uint4*>(p.y + go0 + (size_t)i * gstep) = c;
+                // non-temporal: the result is far larger than the L2 and is read next by another kernel; allocating its lines there only
+                // evicts the operands the neighbouring tiles share (A/B: -0.18 ms per train step, -0.16 ms per epoch-tail forward)
+                __builtin_nontemporal_store(cv_u32x4{c.x, c.y, c.z, c.w}, reinterpret_cast<cv_u32x4*>(p.y + go0 + (size_t)i * gstep));
             }
         }
         cv_epilogue_stats<BN>(p, ssum, ssq, Ss, t, n0, mt);
@@ -210,16 +212,18 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
         const __amdgpu_buffer_rsrc_t r_bnx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bnx), (short)0, p.bnx ? (int)ybytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask_bits), (short)0, p.mask_bits ? (int)(ybytes >> 4) : 0, 0x00020000);
         const uint32_t gob = (uint32_t)go0 * 2u, gsb = (uint32_t)gstep * 2u;     // byte offsets of the thread's first row chunk / row step
+        // (aux 2 on the 16-byte operand loads = non-temporal: each is read once by this launch; A/B -0.05 ms per train step. The same
+        // hint on the K loop's A-operand DMA costs +0.7 ms: the N tiles of a row block share those lines through the L2.)
         cv_u32x4 f_add[2][HALF], f_mask[2][HALF], f_bnx[2][HALF];
         uint32_t f_bits[2][HALF];
 #define CV_EPI_LOAD(set, hh_)                                                                                   \
         _Pragma("unroll")                                                                                       \
         for (int ii = 0; ii < HALF; ++ii) {                                                                     \
             const uint32_t ob = gob + (uint32_t)((hh_) * HALF + ii) * gsb;                                      \
-            f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)ob, 0, 0);                       \
-            f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 0);                     \
+            f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)ob, 0, 2);                       \
+            f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 2);                     \
             f_bits[set][ii] = __builtin_amdgcn_raw_buffer_load_b8(r_bits, (int)(ob >> 4), 0, 0);                \
-            f_bnx[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_bnx, (int)ob, 0, 0);                       \
+            f_bnx[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_bnx, (int)ob, 0, 2);                       \
         }
         CV_EPI_LOAD(0, 0);
         mask_coefficients();                                    // (its loads travel together with the first batch's)
@@ -264,7 +268,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                         if (!(bb & (2u << (2 * q2)))) cw[q2] &= 0x0000ffffu;
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{cw[0], cw[1], cw[2], cw[3]}, r_y, (int)(gob + (uint32_t)i * gsb), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{cw[0], cw[1], cw[2], cw[3]}, r_y, (int)(gob + (uint32_t)i * gsb), 0, 2);   // (aux 2 = non-temporal, as below: -0.14 ms)
                 if (p.bnx) {
                     const uint32_t xw[4] = {f_bnx[set][ii].x, f_bnx[set][ii].y, f_bnx[set][ii].z, f_bnx[set][ii].w};
 #pragma unroll
@@ -372,7 +376,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                     }
                     c = make_uint4(cw[0], cw[1], cw[2], cw[3]);
                 }
-                *reinterpret_cast<uint4*>(p.y + orow[ii]) = c;
+                __builtin_nontemporal_store(cv_u32x4{c.x, c.y, c.z, c.w}, reinterpret_cast<cv_u32x4*>(p.y + orow[ii]));
                 if (p.bnx) {
                     const uint32_t gw[4] = {c.x, c.y, c.z, c.w};
                     const uint32_t xw[4] = {v_bnx[ii].x, v_bnx[ii].y, v_bnx[ii].z, v_bnx[ii].w};
