@@ -115,7 +115,7 @@ stem_conv_kernel(StemP p) {
             const int px = srow + 32 * i;
             if (px < p.Wo) {
                 const u32x4 c = *reinterpret_cast<const u32x4*>(cs + px * ST_CS_STRIDE + sch * 16);
-                *reinterpret_cast<u32x4*>(yrow + (size_t)px * ST_COUT + sch * 8) = c;
+                __builtin_nontemporal_store(c, reinterpret_cast<u32x4*>(yrow + (size_t)px * ST_COUT + sch * 8));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float f0 = __uint_as_float(c[q] << 16), f1 = __uint_as_float(c[q] & 0xffff0000u);
