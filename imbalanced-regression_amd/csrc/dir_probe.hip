@@ -14,12 +14,17 @@ typedef __attribute__((ext_vector_type(16))) float pb_f32x16;
 
 // A workgroup moves 16 KB contiguous blocks (4 x 4 KB wave-rows), blocks dealt round-robin to the workgroups: no
 // power-of-two stride between the loads a lane has in flight (a 8 MB stride parks them all on one HBM channel).
+// Streaming probes: non-temporal loads and stores (tools/stream/stream_variants.hip: 6.5 TB/s for the copy against 5.9 with plain
+// accesses; issue order and depth per lane make no difference) — the best rate a kernel of this shape reaches, i.e. the yardstick.
+typedef __attribute__((ext_vector_type(4))) float pb_f32x4;
+__device__ __forceinline__ float4 pb_ldnt(const float4* p) { const pb_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pb_f32x4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void pb_stnt(float4* p, float4 v) { __builtin_nontemporal_store(pb_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pb_f32x4*>(p)); }
 __global__ void __launch_bounds__(DIR_TPB) probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
     const size_t nblk = n4 / (4 * DIR_TPB);
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
-        const float4 a = src[i], b = src[i + DIR_TPB], c = src[i + 2 * DIR_TPB], d = src[i + 3 * DIR_TPB];
-        dst[i] = a; dst[i + DIR_TPB] = b; dst[i + 2 * DIR_TPB] = c; dst[i + 3 * DIR_TPB] = d;
+        const float4 a = pb_ldnt(src + i), b = pb_ldnt(src + i + DIR_TPB), c = pb_ldnt(src + i + 2 * DIR_TPB), d = pb_ldnt(src + i + 3 * DIR_TPB);
+        pb_stnt(dst + i, a); pb_stnt(dst + i + DIR_TPB, b); pb_stnt(dst + i + 2 * DIR_TPB, c); pb_stnt(dst + i + 3 * DIR_TPB, d);
     }
     for (size_t i = nblk * (4 * DIR_TPB) + (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * DIR_TPB) dst[i] = src[i];
 }
@@ -29,7 +34,7 @@ __global__ void __launch_bounds__(DIR_TPB) probe_read_kernel(const float4* __res
     float acc = 0.0f;
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
-        const float4 a = src[i], b = src[i + DIR_TPB], c = src[i + 2 * DIR_TPB], d = src[i + 3 * DIR_TPB];
+        const float4 a = pb_ldnt(src + i), b = pb_ldnt(src + i + DIR_TPB), c = pb_ldnt(src + i + 2 * DIR_TPB), d = pb_ldnt(src + i + 3 * DIR_TPB);
         acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
     }
     for (size_t i = nblk * (4 * DIR_TPB) + (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * DIR_TPB) {
@@ -45,7 +50,7 @@ __global__ void __launch_bounds__(DIR_TPB) probe_write_kernel(float4* __restrict
     const float4 x = make_float4(v, v + 1.0f, v + 2.0f, v + 3.0f);
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const size_t i = blk * (4 * DIR_TPB) + threadIdx.x;
-        dst[i] = x; dst[i + DIR_TPB] = x; dst[i + 2 * DIR_TPB] = x; dst[i + 3 * DIR_TPB] = x;
+        pb_stnt(dst + i, x); pb_stnt(dst + i + DIR_TPB, x); pb_stnt(dst + i + 2 * DIR_TPB, x); pb_stnt(dst + i + 3 * DIR_TPB, x);
     }
 }
 
