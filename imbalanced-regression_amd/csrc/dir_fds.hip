@@ -239,9 +239,14 @@ fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbit
 }
 
 // P: piece x column-tile partial sums in float64 registers. VEC = 4 (16 B per lane) or 1.
+// non-temporal 16-byte load / store: feature rows are read once per pass and are far larger than the L2
+typedef __attribute__((ext_vector_type(4))) float fds_f32x4;
+__device__ __forceinline__ float4 fds_ldnt(const float* p) { const fds_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fds_f32x4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float fds_ldnt1(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void fds_stnt(float* p, const float4& v) { __builtin_nontemporal_store(fds_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<fds_f32x4*>(p)); }
 template <int VEC> struct FVec;
-template <> struct FVec<4> { using T = float4; };
-template <> struct FVec<1> { using T = float; };
+template <> struct FVec<4> { using T = float4; static __device__ __forceinline__ float4 ldnt(const float* p) { return fds_ldnt(p); } };
+template <> struct FVec<1> { using T = float; static __device__ __forceinline__ float ldnt(const float* p) { return fds_ldnt1(p); } };
 template <int VEC> __device__ __forceinline__ void fvec_get(const typename FVec<VEC>::T& v, float (&o)[VEC]);
 template <> __device__ __forceinline__ void fvec_get<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 template <> __device__ __forceinline__ void fvec_get<1>(const float& v, float (&o)[1]) { o[0] = v; }
@@ -269,7 +274,7 @@ fds_piece_sums_kernel(const float* __restrict__ feats, int C,
         V v[PIECE_UNROLL];
 #pragma unroll
         for (int u = 0; u < PIECE_UNROLL; ++u)              // 8 independent 16-B loads in flight per lane
-            v[u] = *reinterpret_cast<const V*>(feats + (size_t)perm[p + u] * C + col);
+            v[u] = FVec<VEC>::ldnt(feats + (size_t)perm[p + u] * C + col);
 #pragma unroll
         for (int u = 0; u < PIECE_UNROLL; ++u) {
             float x[VEC]; fvec_get<VEC>(v[u], x);
@@ -278,7 +283,7 @@ fds_piece_sums_kernel(const float* __restrict__ feats, int C,
         }
     }
     for (; p < p1; ++p) {
-        float x[VEC]; fvec_get<VEC>(*reinterpret_cast<const V*>(feats + (size_t)perm[p] * C + col), x);
+        float x[VEC]; fvec_get<VEC>(FVec<VEC>::ldnt(feats + (size_t)perm[p] * C + col), x);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { const double d = (double)x[j] - kd[j]; s1[j] += d; s2[j] += d * d; }
     }
@@ -313,7 +318,7 @@ fds_piece_sums_narrow_kernel(const float* __restrict__ feats, int C, int tpr,
         for (; p + 3 * rl < p1; p += 4 * rl) {
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(feats + (size_t)perm[p + u * rl] * C + col);
+            for (int u = 0; u < 4; ++u) v[u] = fds_ldnt(feats + (size_t)perm[p + u * rl] * C + col);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double d0 = (double)v[u].x - kd[0], d1 = (double)v[u].y - kd[1], d2 = (double)v[u].z - kd[2], d3 = (double)v[u].w - kd[3];
@@ -321,7 +326,7 @@ fds_piece_sums_narrow_kernel(const float* __restrict__ feats, int C, int tpr,
             }
         }
         for (; p < p1; p += rl) {
-            const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)perm[p] * C + col);
+            const float4 v = fds_ldnt(feats + (size_t)perm[p] * C + col);
             const double d0 = (double)v.x - kd[0], d1 = (double)v.y - kd[1], d2 = (double)v.z - kd[2], d3 = (double)v.w - kd[3];
             s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
         }
@@ -615,13 +620,13 @@ fds_calibrate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
     if (VEC == 4) {
         const int col = (blockIdx.y * DIR_TPB + threadIdx.x) * 4;
         if (col >= C) return;
-        float4 g = *reinterpret_cast<const float4*>(dy + xo + col);
+        float4 g = fds_ldnt(dy + xo + col);
         if (bin >= 0) {
             const float4 s = *reinterpret_cast<const float4*>(scale + to + col);
             g.x = s.x < 0.0f ? g.x : g.x * s.x; g.y = s.y < 0.0f ? g.y : g.y * s.y;
             g.z = s.z < 0.0f ? g.z : g.z * s.z; g.w = s.w < 0.0f ? g.w : g.w * s.w;
         }
-        *reinterpret_cast<float4*>(dx + xo + col) = g;
+        fds_stnt(dx + xo + col, g);
     } else {
         const int col = blockIdx.y * DIR_TPB + threadIdx.x;
         if (col >= C) return;
@@ -646,23 +651,23 @@ fds_calibrate_narrow_kernel(float* __restrict__ x, const float* __restrict__ dy,
         const int bin = bins[row];
         const size_t xo = (size_t)row * C + col;
         if (BWD) {
-            float4 g = *reinterpret_cast<const float4*>(dy + xo);
+            float4 g = fds_ldnt(dy + xo);
             if (bin >= 0) {
                 const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)bin * C + col);
                 g.x = sc.x < 0.0f ? g.x : g.x * sc.x; g.y = sc.y < 0.0f ? g.y : g.y * sc.y;
                 g.z = sc.z < 0.0f ? g.z : g.z * sc.z; g.w = sc.w < 0.0f ? g.w : g.w * sc.w;
             }
-            *reinterpret_cast<float4*>(x + xo) = g;
+            fds_stnt(x + xo, g);
         } else {
             if (bin < 0) continue;
             const size_t to = (size_t)bin * C + col;
-            float4 v = *reinterpret_cast<float4*>(x + xo);
+            float4 v = fds_ldnt(x + xo);
             const float4 a = *reinterpret_cast<const float4*>(m1 + to);
             const float4 sc = *reinterpret_cast<const float4*>(scale + to);
             const float4 c = *reinterpret_cast<const float4*>(m2 + to);
             v.x = calib1(v.x, a.x, sc.x, c.x); v.y = calib1(v.y, a.y, sc.y, c.y);
             v.z = calib1(v.z, a.z, sc.z, c.z); v.w = calib1(v.w, a.w, sc.w, c.w);
-            *reinterpret_cast<float4*>(x + xo) = v;
+            fds_stnt(x + xo, v);
         }
     }
 }
