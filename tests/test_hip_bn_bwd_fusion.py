@@ -49,6 +49,8 @@ def _expected_sums(y, link):
     (8, 64, 256, 56, 1, "addend+mask"),  # conv1 data gradient + shortcut gradient + deferred ReLU -> previous bn3 sums
     (3, 128, 512, 28, 1, "addend"),
     (5, 1024, 256, 14, 1, ""),           # M = 980: last 128-row tile is partial
+    (5, 64, 256, 14, 1, "addend+mask"),  # ... with every fused operand: the rows beyond M fall outside the buffer descriptors' range
+    (3, 128, 128, 14, 3, "addend"),      # patch-staged 3x3: every tile is 98 of 128 rows
 ])
 def test_dgrad_epilogue_sums_vs_float64(n, cy, cx, hw, k, extras, recompute):
     from dirhip.conv import conv2d_igemm
