@@ -449,6 +449,102 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
     }
 }
 
+// ---- backward of the projection-shortcut join relu(bn(x) + bn_r(r)) on its (already masked) gradient g: both BatchNorms
+// share g, so ONE reduction pass forms (sum g, sum g x) and (sum g, sum g r) — two ordinary partial lists — and ONE apply pass
+// writes dx and dr: g is read twice instead of four times (8 tensor passes instead of 10). Same row order and accumulation order as
+// bn_bwd_partial_kernel<T, 0> / bn_bwd_apply_kernel<T, 0, false>: the results are bit-identical to two dir_bn_bwd calls.
+template <typename T>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_bwd_join_partial_kernel(const T* __restrict__ gout, const T* __restrict__ x, const T* __restrict__ r, int64_t M, int C, BnGeom g,
+                           float* __restrict__ partial_x, float* __restrict__ partial_r) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c0 = blockIdx.y * g.ct, c = c0 + tg * VEC;
+    float ax[2][VEC], ar[2][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ax[0][j] = 0.0f; ax[1][j] = 0.0f; ar[0][j] = 0.0f; ar[1][j] = 0.0f; }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + stride < M; row += 2 * stride) {
+        float d[2][VEC], v[2][VEC], w[2][VEC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Vec<T>::load(gout + (row + u * stride) * C + c, d[u]);
+            Vec<T>::load(x + (row + u * stride) * C + c, v[u]);
+            Vec<T>::load(r + (row + u * stride) * C + c, w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { ax[0][j] += d[u][j]; ax[1][j] += d[u][j] * v[u][j]; ar[1][j] += d[u][j] * w[u][j]; }
+    }
+    for (; row < M; row += stride) {
+        float d[VEC], v[VEC], w[VEC];
+        Vec<T>::load(gout + row * C + c, d);
+        Vec<T>::load(x + row * C + c, v);
+        Vec<T>::load(r + row * C + c, w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { ax[0][j] += d[j]; ax[1][j] += d[j] * v[j]; ar[1][j] += d[j] * w[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ar[0][j] = ax[0][j];
+    block_reduce_store<VEC, 2>(ax, g.tpr, g.rpi, C, c0, partial_x, C);
+    __syncthreads();                                     // (the helper's LDS buffer is reused)
+    block_reduce_store<VEC, 2>(ar, g.tpr, g.rpi, C, c0, partial_r, C);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(DIR_TPB)
+bn_bwd_join_apply_kernel(const T* __restrict__ gout, const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ dx,
+                         T* __restrict__ dr, int64_t M, int C, BnGeom g, const float* __restrict__ coef_x, const float* __restrict__ coef_r) {
+    constexpr int VEC = Vec<T>::N;
+    const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
+    const int c = blockIdx.y * g.ct + tg * VEC;
+    float a[VEC], p[VEC], q[VEC], a2[VEC], p2[VEC], q2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        a[j] = coef_x[c + j]; p[j] = coef_x[C + c + j]; q[j] = coef_x[2 * C + c + j];
+        a2[j] = coef_r[c + j]; p2[j] = coef_r[C + c + j]; q2[j] = coef_r[2 * C + c + j];
+    }
+    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
+    for (; row + stride < M; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
+        float d[2][VEC], v[2][VEC], w[2][VEC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t pr = M - 1 - (row + u * stride);
+            Vec<T>::load_nt(gout + pr * C + c, d[u]);
+            Vec<T>::load(x + pr * C + c, v[u]);
+            Vec<T>::load(r + pr * C + c, w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t pr = M - 1 - (row + u * stride);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                v[u][j] = a[j] * d[u][j] + (p[j] * v[u][j] + q[j]);
+                w[u][j] = a2[j] * d[u][j] + (p2[j] * w[u][j] + q2[j]);
+            }
+            Vec<T>::store(dx + pr * C + c, v[u]);
+            Vec<T>::store(dr + pr * C + c, w[u]);
+        }
+    }
+    for (; row < M; row += stride) {
+        const int64_t pr = M - 1 - row;
+        float d[VEC], v[VEC], w[VEC];
+        Vec<T>::load_nt(gout + pr * C + c, d);
+        Vec<T>::load(x + pr * C + c, v);
+        Vec<T>::load(r + pr * C + c, w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            v[j] = a[j] * d[j] + (p[j] * v[j] + q[j]);
+            w[j] = a2[j] * d[j] + (p2[j] * w[j] + q2[j]);
+        }
+        Vec<T>::store(dx + pr * C + c, v);
+        Vec<T>::store(dr + pr * C + c, w);
+    }
+}
+
 struct BnWs { float* partial; float* coef; size_t bytes; };
 template <int VEC> BnWs bn_ws(void* base, int64_t M, int C) {
     BnGeom g = bn_geom<VEC>(M, C);
@@ -593,7 +689,48 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     return DIR_OK;
 }
 
+template <typename T>
+int bwd_join_impl(const void* g_, const void* x_, const void* r_, void* dx_, void* dr_, int64_t M, int C, const float* gamma,
+                  const float* mean, const float* rstd, const float* gamma_r, const float* mean_r, const float* rstd_r, float* dgamma,
+                  float* dbeta, float* dgamma_r, float* dbeta_r, void* ws, size_t ws_bytes, hipStream_t s) {
+    constexpr int VEC = Vec<T>::N;
+    BnGeom g = bn_geom<VEC>(M, C);
+    const size_t one = bn_ws<VEC>(nullptr, M, C).bytes;
+    DIR_RETURN_IF(ws_bytes < 2 * one, DIR_EWORKSPACE);
+    BnWs wx = bn_ws<VEC>(ws, M, C), wr = bn_ws<VEC>(static_cast<char*>(ws) + one, M, C);
+    const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
+    hipLaunchKernelGGL(bn_bwd_join_partial_kernel<T>, grid, blk, 0, s, static_cast<const T*>(g_), static_cast<const T*>(x_),
+                       static_cast<const T*>(r_), M, C, g, wx.partial, wr.partial);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), blk, 0, s, wx.partial, g.rblocks, M, C, gamma, mean, rstd,
+                       dgamma, dbeta, wx.coef);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), blk, 0, s, wr.partial, g.rblocks, M, C, gamma_r, mean_r,
+                       rstd_r, dgamma_r, dbeta_r, wr.coef);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_join_apply_kernel<T>, grid, blk, 0, s, static_cast<const T*>(g_), static_cast<const T*>(x_),
+                       static_cast<const T*>(r_), static_cast<T*>(dx_), static_cast<T*>(dr_), M, C, g, wx.coef, wr.coef);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
 }  // namespace
+
+extern "C" int dir_bn_bwd_join(const void* g, const void* x, const void* r, void* dx, void* dr, int dtype, int64_t M, int C,
+                               const float* gamma, const float* save_mean, const float* save_rstd, const float* gamma_r,
+                               const float* save_mean_r, const float* save_rstd_r, float* dgamma, float* dbeta, float* dgamma_r,
+                               float* dbeta_r, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!g || !x || !r || !dx || !dr || !gamma || !save_mean || !save_rstd || !gamma_r || !save_mean_r || !save_rstd_r, DIR_EINVAL);
+    DIR_RETURN_IF(!dgamma || !dbeta || !dgamma_r || !dbeta_r || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32 && dtype != DIR_BF16, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!bn_shape_ok(dtype, M, C), DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(!dir_aligned16(g) || !dir_aligned16(x) || !dir_aligned16(r) || !dir_aligned16(dx) || !dir_aligned16(dr), DIR_EINVAL);
+    if (dtype == DIR_BF16)
+        return bwd_join_impl<bf16_t>(g, x, r, dx, dr, M, C, gamma, save_mean, save_rstd, gamma_r, save_mean_r, save_rstd_r, dgamma, dbeta,
+                                     dgamma_r, dbeta_r, workspace, workspace_bytes, dir_s(stream));
+    return bwd_join_impl<float>(g, x, r, dx, dr, M, C, gamma, save_mean, save_rstd, gamma_r, save_mean_r, save_rstd_r, dgamma, dbeta,
+                                dgamma_r, dbeta_r, workspace, workspace_bytes, dir_s(stream));
+}
 
 extern "C" size_t dir_bn_workspace(int dtype, int64_t M, int C) {
     if (!bn_shape_ok(dtype, M, C)) return 0;

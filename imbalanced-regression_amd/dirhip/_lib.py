@@ -49,6 +49,7 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_bn_bwd_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_bn_bwd_join": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_int] + [c_void_p] * 11 + [c_size_t, c_void_p]),
     "dir_conv_dgrad_ex": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p] * 7),
     "dir_bn_fwd_train_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

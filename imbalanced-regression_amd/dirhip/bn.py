@@ -191,10 +191,19 @@ class _BNJoinFn(torch.autograd.Function):
         f32 = torch.float32
         dx, dr = torch.empty_like(x), torch.empty_like(r)
         dgamma, dbeta, dgamma_r, dbeta_r = (torch.empty(c, dtype=f32, device=dev) for _ in range(4))
-        ws = _ws(code, m, c, dev)
         link = ctx.deferred
+        if (not ctx.relu or (link is not None and link[0])) and _JOIN_BWD[0]:
+            # no ReLU, or its backward was applied by the consumer (bn_act doc): dout is the gradient of both BatchNorms as it stands —
+            # one reduction pass and one apply pass for the pair
+            n_ws = 2 * L.lib().dir_bn_workspace(code, m, c)
+            ws2 = torch.empty(n_ws, dtype=torch.uint8, device=dev)
+            L.check(L.lib().dir_bn_bwd_join(L.ptr(dout), L.ptr(x), L.ptr(r), L.ptr(dx), L.ptr(dr), code, m, c, L.ptr(gamma), L.ptr(mean),
+                                            L.ptr(rstd), L.ptr(gamma_r), L.ptr(mean_r), L.ptr(rstd_r), L.ptr(dgamma), L.ptr(dbeta),
+                                            L.ptr(dgamma_r), L.ptr(dbeta_r), L.ptr(ws2), n_ws, stream), "dir_bn_bwd_join")
+            return (dx, dgamma, dbeta, None, None, None, None, None, dr, dgamma_r, dbeta_r, None, None, None, None, None, None, None, None)
+        ws = _ws(code, m, c, dev)
         if not ctx.relu or (link is not None and link[0]):
-            g = dout                                         # no ReLU, or its backward was applied by the consumer (bn_act doc)
+            g = dout
             L.check(L.lib().dir_bn_bwd(L.ptr(g), L.ptr(x), None, L.ptr(dx), None, code, m, c, L.ptr(gamma), L.ptr(beta),
                                        L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(ws), ws.numel(), stream),
                     "dir_bn_bwd")
@@ -207,6 +216,17 @@ class _BNJoinFn(torch.autograd.Function):
                                    L.ptr(mean_r), L.ptr(rstd_r), L.ptr(dgamma_r), L.ptr(dbeta_r), 0, L.ptr(ws), ws.numel(), stream),
                 "dir_bn_bwd")
         return (dx, dgamma, dbeta, None, None, None, None, None, dr, dgamma_r, dbeta_r, None, None, None, None, None, None, None, None)
+
+
+# The join's two BatchNorm backwards as one reduction + one apply pass (dir_bn_bwd_join). Off = two dir_bn_bwd calls (tests compare).
+_JOIN_BWD = [True]
+
+
+def set_join_bwd(enabled):
+    """Returns the previous setting."""
+    prev = _JOIN_BWD[0]
+    _JOIN_BWD[0] = bool(enabled)
+    return prev
 
 
 # The deferred ReLU backward reads its mask as one bit per element (emitted by the forward) instead of the bf16 tensor itself.

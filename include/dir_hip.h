@@ -227,6 +227,14 @@ int dir_bn_fwd_train_bits(const void* x, const void* residual, void* y, int64_t 
                           size_t workspace_bytes, dir_stream_t stream);
 int dir_bn_apply_bits(const void* x, const void* residual, const float* residual_coef, void* y, int64_t M, int C,
                       const float* coef, void* relu_bits_out, dir_stream_t stream);
+/* Backward of the projection-shortcut join relu(bn3(x) + bn_d(r)) (imdb-wiki-dir/resnet.py:63-68) on its gradient g with the
+ * ReLU backward ALREADY applied (the consumer's data-gradient kernel masked it, dir_conv_dgrad_ex): both BatchNorm backwards in
+ * one reduction pass + one apply pass — g is read twice instead of four times; bit-identical to two dir_bn_bwd(relu = 0) calls.
+ * workspace: 2 x dir_bn_workspace(dtype, M, C) bytes. */
+int dir_bn_bwd_join(const void* g, const void* x, const void* r, void* dx, void* dr, int dtype, int64_t M, int C,
+                    const float* gamma, const float* save_mean, const float* save_rstd, const float* gamma_r,
+                    const float* save_mean_r, const float* save_rstd_r, float* dgamma, float* dbeta, float* dgamma_r,
+                    float* dbeta_r, void* workspace, size_t workspace_bytes, dir_stream_t stream);
 /* dir_bn_bwd minus its first pass: the per-channel sums of g and g*x arrive as `partial` [partial_rows][2][C] f32 from the
  * data-gradient kernel that produced dout (dir_conv_dgrad_bnstats / dir_conv_dgrad_s2_bnstats), so dout and x are read once
  * (apply pass) instead of twice.  relu != 0: ReLU layer without residual, mask recomputed from x (as dir_bn_bwd with

@@ -194,6 +194,38 @@ def test_bn_join_matches_two_separate_batchnorms(deferred):
     assert int(bn.num_batches_tracked) == 1 and int(bn_r.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("shape,dtype", [((8, 256, 56, 56), torch.bfloat16), ((6, 1024, 14, 14), torch.bfloat16), ((3, 2048, 7, 7), torch.bfloat16),
+                                         ((2, 128, 9, 5), torch.float32)])
+def test_bn_join_backward_one_pass_pair_is_bit_identical_to_two_backwards(shape, dtype):
+    """dir_bn_bwd_join (one reduction + one apply pass for both BatchNorms of the join) vs two dir_bn_bwd(relu = 0) calls on the
+    masked gradient: same row order, same accumulation order -> the same bits everywhere."""
+    from dirhip import bn as B
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    c = shape[1]
+    x0 = torch.randn(shape, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    r0 = (torch.randn(shape, device="cuda", generator=g) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(shape, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    got = {}
+    for on in (True, False):
+        prev = B.set_join_bwd(on)
+        try:
+            bn, bn_r = nn.BatchNorm2d(c).cuda(), nn.BatchNorm2d(c).cuda()
+            gg = torch.Generator(device="cuda").manual_seed(7)
+            with torch.no_grad():
+                for m_ in (bn, bn_r):
+                    m_.weight.copy_(torch.rand(c, device="cuda", generator=gg) + 0.5)
+                    m_.bias.copy_(torch.randn(c, device="cuda", generator=gg) * 0.1)
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            y = B.bn_join(x, bn, None, r, bn_r, None, relu=True, defer_relu_grad=True)
+            y._dir_relu_flag[0] = True                                   # the consumer applied the ReLU backward
+            y.backward(torch.where(y > 0, dy, torch.zeros_like(dy)))
+            got[on] = [t.detach().clone() for t in (x.grad, r.grad, bn.weight.grad, bn.bias.grad, bn_r.weight.grad, bn_r.bias.grad)]
+        finally:
+            B.set_join_bwd(prev)
+    for a, b, name in zip(got[True], got[False], ("dx", "dr", "dgamma", "dbeta", "dgamma_r", "dbeta_r")):
+        assert torch.equal(a, b), name
+
+
 def test_stem_bn_relu_maxpool_matches_unfused():
     """Fused stem tail vs torch fp32 BatchNorm -> ReLU -> MaxPool2d(3, 2, 1)."""
     from dirhip.pool import bn_relu_maxpool
