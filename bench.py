@@ -556,7 +556,7 @@ def main():
             # (3.11 M elements per image); for the other 43 BatchNorms it runs inside the data-gradient epilogues (conv family)
             alg = (5 * 11.11e6 + 2 * 3.11e6) * args.batch * 2
             a = alg / (fam["batchnorm"]["us_per_step"] * 1e-6) / 1e9
-            kr.append({"kernel": "dir_bn_* family (apply / join / backward apply + the 9 remaining reductions + finalize), in situ", "bound": "hbm",
+            kr.append({"kernel": "dir_bn_* family (apply / join / backward apply + the 5 remaining reduction passes (last bn3, one per join pair) + finalize), in situ", "bound": "hbm",
                        "ms": fam["batchnorm"]["us_per_step"] / 1e3, "algorithmic_bytes": alg, "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": a / PEAK_HBM_GBS, "frac_of_measured_peak": a / peaks["stream_copy_GBs"]})
         if "tail" in fam:

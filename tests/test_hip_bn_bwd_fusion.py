@@ -286,9 +286,9 @@ def test_whole_model_fused_vs_three_pass_bn_backward():
             R.set_bn_bwd_fusion(prev)
         res[fused] = (out, {n: p.grad.detach().double().clone() for n, p in model.named_parameters()})
 
-    def n_partial(c):
-        return sum(v for k, v in c.items() if "bn_bwd_partial_kernel" in k)
-    assert n_partial(counts[False]) == 52 and n_partial(counts[True]) == 9, (n_partial(counts[False]), n_partial(counts[True]))
+    def n_partial(c):                               # (reduction passes of single BatchNorms, of the four joins' pairs)
+        return (sum(v for k, v in c.items() if "bn_bwd_partial_kernel" in k), sum(v for k, v in c.items() if "bn_bwd_join_partial_kernel" in k))
+    assert n_partial(counts[False]) == (44, 4) and n_partial(counts[True]) == (1, 4), (n_partial(counts[False]), n_partial(counts[True]))
     assert torch.equal(res[True][0], res[False][0])
     rels = {n: float((res[True][1][n] - res[False][1][n]).norm() / res[False][1][n].norm().clamp_min(1e-300)) for n in res[True][1]}
     worst = sorted(rels.items(), key=lambda kv: -kv[1])[:5]
