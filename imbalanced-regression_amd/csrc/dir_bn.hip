@@ -46,6 +46,7 @@ template <> struct Vec<float> {
         const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
     static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+    static __device__ __forceinline__ uint32_t store_bits(float* p, const float (&o)[4]) { store(p, o); return 0u; }
     // non-temporal load: the last read of a stream much larger than the L2 — its lines are not worth keeping there
     static __device__ __forceinline__ void load_nt(const float* p, float (&o)[4]) {
         typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -82,6 +83,23 @@ template <> struct Vec<bf16_t> {
             w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
         }
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // store + the ReLU mask byte of the STORED values: bit j = (halfword j, as a signed number, > 0) = "stored value > 0" for every
+    // non-NaN value; read off the packed words, no second rounding of the eight elements
+    static __device__ __forceinline__ uint32_t store_bits(bf16_t* p, const float (&o)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const f32x2_t v = {o[2 * i], o[2 * i + 1]};
+            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+        }
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b |= (((int32_t)(w[i] << 16) > 0 ? 1u : 0u) | ((int32_t)(w[i] & 0xffff0000u) > 0 ? 2u : 0u)) << (2 * i);
+        return b;
     }
 };
 
@@ -288,8 +306,9 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
                 if (RELU) o = o > 0.0f ? o : 0.0f;
                 v[u][j] = o;
             }
-            Vec<T>::store(y + (M - 1 - (row + u * stride)) * C + c, v[u]);
-            if (RELU && bits) bits[((M - 1 - (row + u * stride)) * C + c) / 8] = relu_bits<T>(v[u]);
+            const uint32_t mb = Vec<T>::store_bits(y + (M - 1 - (row + u * stride)) * C + c, v[u]);
+            if (RELU && bits) bits[((M - 1 - (row + u * stride)) * C + c) / 8] = (uint8_t)mb;
+
         }
     }
     for (; row < M; row += stride) {
@@ -304,8 +323,9 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
             if (RELU) o = o > 0.0f ? o : 0.0f;
             v[j] = o;
         }
-        Vec<T>::store(y + (M - 1 - row) * C + c, v);
-        if (RELU && bits) bits[((M - 1 - row) * C + c) / 8] = relu_bits<T>(v);
+        const uint32_t mb = Vec<T>::store_bits(y + (M - 1 - row) * C + c, v);
+        if (RELU && bits) bits[((M - 1 - row) * C + c) / 8] = (uint8_t)mb;
+
     }
 }
 
