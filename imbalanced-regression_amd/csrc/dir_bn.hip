@@ -256,15 +256,8 @@ bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __r
 }
 
 // One byte per 8-channel group of a ReLU output row: bit j = (the STORED value of channel j) > 0 — the mask of that ReLU's
-// backward at 1/16 of the bytes of the tensor itself (bf16 only; a positive float that rounds to bf16 zero counts as zero).
-template <typename T> __device__ __forceinline__ uint8_t relu_bits(const float (&o)[Vec<T>::N]);
-template <> __device__ __forceinline__ uint8_t relu_bits<float>(const float (&)[4]) { return 0; }
-template <> __device__ __forceinline__ uint8_t relu_bits<bf16_t>(const float (&o)[8]) {
-    uint32_t b = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b |= (__uint_as_float(f2bf(o[j]) << 16) > 0.0f ? 1u : 0u) << j;
-    return (uint8_t)b;
-}
+// backward at 1/16 of the bytes of the tensor itself (bf16 only; a positive float that rounds to bf16 zero counts as zero):
+// Vec<bf16_t>::store_bits above.
 
 // ---- forward: y = [relu]( x * a + b [+ residual] ) ---------------------------------------------------------
 // RES: 0 = no residual, 1 = residual tensor added as is, 2 = residual is itself the INPUT of a BatchNorm whose
