@@ -78,7 +78,11 @@ __device__ __forceinline__ void wg_transpose_store(unsigned char* tile, const ui
     }
 }
 
-template <int TM, int TN>
+// PF = prefetch distance of the global loads in K-steps (2 for the 128 x 128 tile, which runs two workgroups per CU anyway: 248
+// registers; the narrower tiles would drop from three to two workgroups per CU with the second register set)
+// SIMPLE = 1x1 / stride 1 / pad 0 (row m of X is row m of the GEMM): a compile-time switch, because a run-time branch around the
+// loads makes the compiler's wait counts conservative again.
+template <int TM, int TN, bool SIMPLE, int PF = (TM == 128 && TN == 128) ? 2 : 1>
 __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(2)))
 conv_wgrad_kernel(WgP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,7 +114,7 @@ conv_wgrad_kernel(WgP p) {
     int ks1 = ks0 + p.ksteps_per_split; if (ks1 > p.ksteps_total) ks1 = p.ksteps_total;
 
     // loader roles: A chunk column ca / row group ga (threads < 2*TM), B chunk column cb / row group gb (threads < 2*TN)
-    const bool doA = t < 2 * TM, doB = t < 2 * TN;
+    const bool doA = (2 * TM >= DIR_TPB) || t < 2 * TM, doB = (2 * TN >= DIR_TPB) || t < 2 * TN;   // (compile-time true for 128-wide tiles)
     const int ca = t % CA, ga = t / CA, cb = t % CB, gb = t / CB;
 
     // ---- everything that depends only on the thread is computed once and pinned in registers: the K loop then issues
@@ -151,7 +155,7 @@ conv_wgrad_kernel(WgP p) {
         asm volatile("" : "+v"(voa[j])); asm volatile("" : "+v"(vob[j]));
     }
     WgWalk walk = {0, 0, 0, 0};
-    if (!p.simple && doB) {                                       // decode the first row of this thread once
+    if (!SIMPLE && doB) {                                       // decode the first row of this thread once
         const int mm = ks0 * WG_BK + 4 * gb;
         int q1 = (int)((float)mm * p.inv_wo); int wo = mm - q1 * p.Wo;
         if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
@@ -161,42 +165,48 @@ conv_wgrad_kernel(WgP p) {
         walk.off = (((n * p.H + walk.hs + trp) * p.W + walk.ws + tsp) * p.Cin + ci0 + cb * 8) * 2;
     }
 
-    u32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-    a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = (u32x4){0u, 0u, 0u, 0u};
+    // Two register sets (P, Q): the global loads of K-step k + 2 are issued at the start of step k — a K-step's loads have two
+    // MFMA steps to arrive instead of one (the loop is bound by that latency, ~1.5-2 us under load against 0.25-0.7 us per step).
+    // Loads of steps beyond the workgroup's K range go out of range (zeros, no memory access) instead of being branched around:
+    // the wait counter is in issue order, and only with unconditional loads can the compiler wait for "all but the newest 8".
+    u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = (u32x4){0u, 0u, 0u, 0u};
 
 #define WG_BL(rs, vo, so) __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)
-#define WG_LOAD(ks)                                                                                               \
+#define WG_LOAD(ks, S)                                                                                            \
     {                                                                                                             \
-        const int mrem = p.M - (ks) * WG_BK;                      /* rows left from this K-step's first row */    \
+        const bool live = (ks) < ks1;                                                                             \
+        const int mrem = live ? p.M - (ks) * WG_BK : 0;           /* rows left from this K-step's first row */    \
         const bool full = mrem >= WG_BK;                                                                          \
         if (doA) {                                                                                                \
-            const int so = (ks) * WG_BK * p.Cout * 2;                                                             \
-            a0 = WG_BL(rs_dy, (full || 4 * ga + 0 < mrem) ? voa[0] : WG_OOB, so);                                 \
-            a1 = WG_BL(rs_dy, (full || 4 * ga + 1 < mrem) ? voa[1] : WG_OOB, so);                                 \
-            a2 = WG_BL(rs_dy, (full || 4 * ga + 2 < mrem) ? voa[2] : WG_OOB, so);                                 \
-            a3 = WG_BL(rs_dy, (full || 4 * ga + 3 < mrem) ? voa[3] : WG_OOB, so);                                 \
+            const int so = live ? (ks) * WG_BK * p.Cout * 2 : 0;                                                  \
+            S##a0 = WG_BL(rs_dy, (full || 4 * ga + 0 < mrem) ? voa[0] : WG_OOB, so);                              \
+            S##a1 = WG_BL(rs_dy, (full || 4 * ga + 1 < mrem) ? voa[1] : WG_OOB, so);                              \
+            S##a2 = WG_BL(rs_dy, (full || 4 * ga + 2 < mrem) ? voa[2] : WG_OOB, so);                              \
+            S##a3 = WG_BL(rs_dy, (full || 4 * ga + 3 < mrem) ? voa[3] : WG_OOB, so);                              \
         }                                                                                                         \
         if (doB) {                                                                                                \
-            if (p.simple) {                                                                                       \
-                const int so = (ks) * WG_BK * p.Cin * 2;                                                          \
-                b0 = WG_BL(rs_x, (full || 4 * gb + 0 < mrem) ? vob[0] : WG_OOB, so);                              \
-                b1 = WG_BL(rs_x, (full || 4 * gb + 1 < mrem) ? vob[1] : WG_OOB, so);                              \
-                b2 = WG_BL(rs_x, (full || 4 * gb + 2 < mrem) ? vob[2] : WG_OOB, so);                              \
-                b3 = WG_BL(rs_x, (full || 4 * gb + 3 < mrem) ? vob[3] : WG_OOB, so);                              \
+            if (SIMPLE) {                                                                                         \
+                const int so = live ? (ks) * WG_BK * p.Cin * 2 : 0;                                               \
+                S##b0 = WG_BL(rs_x, (full || 4 * gb + 0 < mrem) ? vob[0] : WG_OOB, so);                           \
+                S##b1 = WG_BL(rs_x, (full || 4 * gb + 1 < mrem) ? vob[1] : WG_OOB, so);                           \
+                S##b2 = WG_BL(rs_x, (full || 4 * gb + 2 < mrem) ? vob[2] : WG_OOB, so);                           \
+                S##b3 = WG_BL(rs_x, (full || 4 * gb + 3 < mrem) ? vob[3] : WG_OOB, so);                           \
             } else {                                                                                              \
                 WgWalk w = walk;                                                                                  \
-                b0 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
-                b1 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
-                b2 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);                  \
-                b3 = wg_gather(rs_x, w, p, trp, tsp);                                                             \
+                if (!live) w.n = p.N;                             /* (wg_gather sends n >= N out of range) */     \
+                S##b0 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);               \
+                S##b1 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);               \
+                S##b2 = wg_gather(rs_x, w, p, trp, tsp); wg_advance(w, p, p.stride, 0, 0, p.cstep);               \
+                S##b3 = wg_gather(rs_x, w, p, trp, tsp);                                                          \
                 wg_advance(walk, p, p.dws64, p.dhs64, p.dn64, p.c64);                                             \
             }                                                                                                     \
         }                                                                                                         \
     }
-#define WG_STORE(buf)                                                                                             \
+#define WG_STORE(buf, S)                                                                                          \
     {                                                                                                             \
-        if (doA) wg_transpose_store(As + (buf) * A_BYTES, aw, a0, a1, a2, a3);                                    \
-        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, bw, b0, b1, b2, b3);                                    \
+        if (doA) wg_transpose_store(As + (buf) * A_BYTES, aw, S##a0, S##a1, S##a2, S##a3);                        \
+        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, bw, S##b0, S##b1, S##b2, S##b3);                        \
     }
     // one K-step on LDS stage `buf` (a literal: the stage offset folds into the instructions' immediate offsets)
 #define WG_MFMA_STEP(buf)                                                                                         \
@@ -224,23 +234,42 @@ conv_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
+    // two K-steps per trip (stages 0 and 1 and the register sets are literals), whole pairs only, the odd last step peeled off
+    // after the loop: a `break` between the halves gives the loop two exits, and the compiler then copies all accumulators
+    // (32 v_mov_b64 per 16 MFMAs, each waiting for its MFMA chain) on every trip
     if (ks0 < ks1) {
-        WG_LOAD(ks0);
-        WG_STORE(0);
-        __syncthreads();
-        // two K-steps per trip (stages 0 and 1 are literals), whole pairs only, the odd last step peeled off after the loop:
-        // a `break` between the halves gives the loop two exits, and the compiler then copies all accumulators (32 v_mov_b64
-        // per 16 MFMAs, each waiting for its MFMA chain) on every trip
         int ks = ks0;
-        for (; ks + 2 <= ks1; ks += 2) {
-            WG_LOAD(ks + 1);                                     // global loads in flight during the MFMAs
-            WG_MFMA_STEP(0);
-            WG_STORE(1);
+        if constexpr (PF == 2) {
+            WG_LOAD(ks0, p);
+            WG_LOAD(ks0 + 1, q);
+            WG_STORE(0, p);
             __syncthreads();
-            if (ks + 2 < ks1) WG_LOAD(ks + 2);
-            WG_MFMA_STEP(1);
-            if (ks + 2 < ks1) WG_STORE(0);
+            for (; ks + 2 <= ks1; ks += 2) {
+                WG_LOAD(ks + 2, p);                              // stage 0 = tile ks, set q = tile ks + 1 (in flight since the last trip)
+                __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks these loads below the stores of set q,
+                WG_MFMA_STEP(0);                                 //  which then wait for them: found in the ISA)
+                WG_STORE(1, q);
+                __syncthreads();
+                WG_LOAD(ks + 3, q);
+                __builtin_amdgcn_sched_barrier(0);
+                WG_MFMA_STEP(1);
+                WG_STORE(0, p);                                  // (tile ks + 2, or zeros past the range: never multiplied)
+                __syncthreads();
+            }
+        } else {
+            WG_LOAD(ks0, p);
+            WG_STORE(0, p);
             __syncthreads();
+            for (; ks + 2 <= ks1; ks += 2) {
+                WG_LOAD(ks + 1, q);                              // global loads in flight during the MFMAs
+                WG_MFMA_STEP(0);
+                WG_STORE(1, q);
+                __syncthreads();
+                WG_LOAD(ks + 2, p);
+                WG_MFMA_STEP(1);
+                WG_STORE(0, p);
+                __syncthreads();
+            }
         }
         if (ks < ks1) WG_MFMA_STEP(0);                           // odd K-step count: the last tile sits in stage 0
     }
@@ -321,7 +350,8 @@ WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
 template <int TM, int TN>
 void wg_launch(const WgP& p, int nblocks, hipStream_t s) {
     constexpr int lds = 2 * (TM + TN) * WG_ROWB;
-    hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN>), dim3(nblocks), dim3(DIR_TPB), lds, s, p);
+    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, true>), dim3(nblocks), dim3(DIR_TPB), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, false>), dim3(nblocks), dim3(DIR_TPB), lds, s, p);
 }
 
 }  // namespace
