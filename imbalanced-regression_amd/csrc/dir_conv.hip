@@ -65,6 +65,10 @@ __device__ __forceinline__ uint32_t cv_f2bf(float f) {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t cv_u32x4;
+// Cache policy `sc1 nt` of a buffer store (aux bits of the raw buffer intrinsics on gfx940+: 1 = sc0, 2 = nt, 16 = sc1). Kept as a
+// compiler-visible intrinsic: an inline-asm store hides its 128-bit data registers from the hazard recognizer (overwritten one
+// instruction later -> corrupted rows, found as NaNs in a BatchNorm's running variance).
+constexpr int CV_AUX_SC1_NT = 18;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // two floats -> packed bf16x2 (round to nearest even, quiet NaN): one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t cv_pack_bf16(float lo, float hi) {
@@ -149,6 +153,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     const size_t gstep = (size_t)RPI * p.Cout;
     const bool full = m0 + CV_BM <= p.M;
     if constexpr (LEAN) {
+        const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, (int)((uint32_t)p.M * (uint32_t)p.Cout * 2u), 0x00020000);
         __syncthreads();
         float ssum[8], ssq[8];
 #pragma unroll
@@ -165,9 +170,10 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                         ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
                     }
                 }
-                // non-temporal: the result is far larger than the L2 and is read next by another kernel; allocating its lines there only
-                // evicts the operands the neighbouring tiles share (A/B: -0.18 ms per train step, -0.16 ms per epoch-tail forward)
-                __builtin_nontemporal_store(cv_u32x4{c.x, c.y, c.z, c.w}, reinterpret_cast<cv_u32x4*>(p.y + go0 + (size_t)i * gstep));
+                // `sc1 nt`: written through to the memory side (where the 256 MB Infinity Cache keeps it for the BatchNorm pass that reads it
+                // next) and streamed past the L2, whose lines are better spent on the operands the neighbouring tiles share. Same-box A/B,
+                // train step / epoch-tail forward: plain store -> `nt` -0.18 / -0.16 ms, `nt` -> `sc1 nt` another -1.17 / -0.37 ms.
+                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{c.x, c.y, c.z, c.w}, r_y, (int)(((uint32_t)go0 + (uint32_t)i * (uint32_t)gstep) * 2u), 0, CV_AUX_SC1_NT);
             }
         }
         cv_epilogue_stats<BN>(p, ssum, ssq, Ss, t, n0, mt);
