@@ -202,7 +202,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
 
     constexpr int HALF = NIT / NBATCH;                          // rows per batch (NBATCH = 4: fewer registers, for the 4-per-CU variant)
-    // Dense rows (every stride-1 launch): the thread's rows in batches, software-pipelined — batch b + 1's operand loads are issued
+    // Every launch but the one with BOTH shortcut-gradient streams: the thread's rows in batches, software-pipelined — batch b + 1's operand loads are issued
     // BEFORE batch b's arithmetic and stores — and free of control flow around the memory instructions: loads and stores are buffer
     // instructions, the descriptor of an operand the launch does not have is EMPTY (out-of-range lanes read zeros / store nothing,
     // without a memory access) and the descriptors end at row M, which also drops the rows of a ragged tile. The wait counter is
@@ -210,10 +210,14 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     // epilogue waits for a store to be acknowledged. With a conditional store or load in between it has to assume the shortest
     // path and emits `s_waitcnt vmcnt(0)` — in the general loop below that is one store round trip per row, eight in a row per
     // workgroup tile (found in the ISA; same-box A/B of the full-tile form: -0.13 ms per train step).
-    if (!decode) {
-        const uint32_t ybytes = (uint32_t)p.M * (uint32_t)p.Cout * 2u;
+    if (!(p.addend && p.addend2)) {
+        // y-shaped operands span the whole result tensor (the scattered rows of a stride-2 class launch index it like y itself)
+        const uint32_t ybytes = p.o2 ? (uint32_t)p.N * (uint32_t)p.OH * (uint32_t)p.OW * (uint32_t)p.Cout * 2u : (uint32_t)p.M * (uint32_t)p.Cout * 2u;
         const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, (int)ybytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.addend), (short)0, p.addend ? (int)ybytes : 0, 0x00020000);
+        // ONE shortcut-gradient stream: the dense one (addend, same offsets as y) or the compact stride-2 one (addend2, own offsets)
+        const uint16_t* addp = p.addend ? p.addend : p.addend2;
+        const uint32_t addbytes = p.addend ? ybytes : (uint32_t)p.N * (uint32_t)(p.Ho >> 1) * (uint32_t)(p.Wo >> 1) * (uint32_t)p.Cout * 2u;
+        const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), (short)0, addp ? (int)addbytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.mask), (short)0, p.mask ? (int)ybytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_bnx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bnx), (short)0, p.bnx ? (int)ybytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask_bits), (short)0, p.mask_bits ? (int)(ybytes >> 4) : 0, 0x00020000);
@@ -221,12 +225,28 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
         // (aux 2 on the 16-byte operand loads = non-temporal: each is read once by this launch; A/B -0.05 ms per train step. The same
         // hint on the K loop's A-operand DMA costs +0.7 ms: the N tiles of a row block share those lines through the L2.)
         cv_u32x4 f_add[2][HALF], f_mask[2][HALF], f_bnx[2][HALF];
-        uint32_t f_bits[2][HALF];
+        uint32_t f_bits[2][HALF], f_ob[2][HALF], f_oa[2][HALF];     // f_ob: byte offset of the row's chunk in y, f_oa: in the addend stream
 #define CV_EPI_LOAD(set, hh_)                                                                                   \
         _Pragma("unroll")                                                                                       \
         for (int ii = 0; ii < HALF; ++ii) {                                                                     \
-            const uint32_t ob = gob + (uint32_t)((hh_) * HALF + ii) * gsb;                                      \
-            f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)ob, 0, 2);                       \
+            uint32_t ob = gob + (uint32_t)((hh_) * HALF + ii) * gsb, oa = ob;                                   \
+            if (decode) {                                         /* (arithmetic only: no memory instruction inside) */ \
+                const int m = m0 + srow + ((hh_) * HALF + ii) * RPI;                                            \
+                int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;                                        \
+                if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }                    \
+                int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;                                        \
+                if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }                      \
+                const bool valid = full || m < p.M;                                                             \
+                if (p.o2) {                                        /* parity class of a stride-2 data gradient: scattered rows */ \
+                    ob = valid ? (uint32_t)((((size_t)n * p.OH + 2 * ho + p.o_a) * p.OW + 2 * wo + p.o_b) * p.Cout + n0 + sch * 8) * 2u : (uint32_t)CV_OOB; \
+                    oa = ob;                                                                                    \
+                }                                                                                               \
+                if (p.addend2)                                     /* rows at even (ho, wo) also receive compact[n, ho/2, wo/2, :] */ \
+                    oa = (valid && !((ho | wo) & 1)) ? (uint32_t)(((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + n0 + sch * 8) * 2u \
+                                                     : (uint32_t)CV_OOB;                                         \
+            }                                                                                                   \
+            f_ob[set][ii] = ob; f_oa[set][ii] = oa;                                                             \
+            f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)oa, 0, 2);                       \
             f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 2);                     \
             f_bits[set][ii] = __builtin_amdgcn_raw_buffer_load_b8(r_bits, (int)(ob >> 4), 0, 0);                \
             f_bnx[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_bnx, (int)ob, 0, 2);                       \
@@ -251,12 +271,15 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                         ssum[2 * q2] += f0; ssq[2 * q2] += f0 * f0; ssum[2 * q2 + 1] += f1; ssq[2 * q2 + 1] += f1 * f1;
                     }
                 }
-                if (p.addend) {                                 // y = bf16(bf16(conv) + addend), like an eager add kernel
+                if (addp) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
                     const uint32_t aw[4] = {f_add[set][ii].x, f_add[set][ii].y, f_add[set][ii].z, f_add[set][ii].w};
+                    const bool has = p.addend || f_oa[set][ii] != (uint32_t)CV_OOB;   // (compact stream: even pixels only; the others keep their bits)
 #pragma unroll
-                    for (int q2 = 0; q2 < 4; ++q2)
-                        cw[q2] = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
-                                              __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const uint32_t sum = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
+                                                          __uint_as_float(cw[q2] & 0xffff0000u) + __uint_as_float(aw[q2] & 0xffff0000u));
+                        cw[q2] = has ? sum : cw[q2];
+                    }
                 }
                 if (p.mask) {                                   // ReLU backward of the tensor this gradient belongs to
                     const uint32_t kw[4] = {f_mask[set][ii].x, f_mask[set][ii].y, f_mask[set][ii].z, f_mask[set][ii].w};
@@ -274,7 +297,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
                         if (!(bb & (2u << (2 * q2)))) cw[q2] &= 0x0000ffffu;
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{cw[0], cw[1], cw[2], cw[3]}, r_y, (int)(gob + (uint32_t)i * gsb), 0, 2);   // (aux 2 = non-temporal, as below: -0.14 ms)
+                __builtin_amdgcn_raw_buffer_store_b128(cv_u32x4{cw[0], cw[1], cw[2], cw[3]}, r_y, (int)f_ob[set][ii], 0, 2);   // (aux 2 = non-temporal, as above: -0.14 ms)
                 if (p.bnx) {
                     const uint32_t xw[4] = {f_bnx[set][ii].x, f_bnx[set][ii].y, f_bnx[set][ii].z, f_bnx[set][ii].w};
 #pragma unroll
@@ -296,7 +319,7 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     }
 
     mask_coefficients();
-    // The general loop (scattered rows of the stride-2 classes, compact stride-2 addend): the thread's rows in
+    // The general loop (only when a dense AND a compact shortcut gradient are given — no layer of ResNet-50 does): the thread's rows in
     // batches, (operand loads of a batch, all in flight together) -> (its arithmetic and stores). The first batch's loads are issued
     // before the barrier that publishes the staging tile. (All rows at once would need 100+ registers.)
 #pragma unroll

@@ -358,6 +358,14 @@ def test_dgrad_join_adds_compact_stride2_gradient_at_even_pixels():
     assert torch.equal(got, ref)
     got_m = conv2d_igemm(x, w, 1, 0, addend_s2=compact, relu_mask=mask)
     assert torch.equal(got_m, torch.where(mask.float() > 0, ref, torch.zeros_like(ref)))
+    # a dense AND a compact shortcut gradient at once (no ResNet-50 layer does; the store loop's general form): dense first, each
+    # addition rounded to bf16 like an eager add kernel
+    dense_add = torch.randn(n, cout, h, h, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    step1 = (dense.float() + dense_add.float()).to(torch.bfloat16)
+    ref2 = step1.clone()
+    ref2[:, :, ::2, ::2] = (step1[:, :, ::2, ::2].float() + compact.float()).to(torch.bfloat16)
+    got2 = conv2d_igemm(x, w, 1, 0, addend=dense_add, addend_s2=compact)
+    assert torch.equal(got2, ref2)
 
 
 @pytest.mark.parametrize("shape", [(4, 3, 224, 224), (2, 3, 64, 40), (3, 3, 18, 8)])
