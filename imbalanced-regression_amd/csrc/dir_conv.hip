@@ -99,11 +99,11 @@ __device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsign
 
 // Epilogue shared by the K-loop variants: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free: the caller
 // has passed a barrier after its last fragment read) -> 16-B row stores with the fused statistics / addend / mask options.
-// Every global operand of the store loop (shortcut gradient, compact stride-2 gradient, ReLU mask, BatchNorm input for the fused
-// backward sums) is fetched for all of the thread's rows BEFORE the barrier that publishes the staging tile — up to 8 rows x 4
-// streams x 16 B in flight per lane while the tile is staged. Written as load-then-use inside the loop, each of them costs a
-// full memory round trip (the compiler keeps `s_waitcnt vmcnt(0)` right behind every load: found in the ISA), 8 x 3 serial
-// round trips per workgroup in the data-gradient launches.
+// The global operands of the store loop (shortcut gradient — dense or compact stride-2 —, ReLU mask as tensor or bits, BatchNorm
+// input for the fused backward sums) are fetched in batches of rows, one batch AHEAD of the arithmetic and stores that consume
+// them and the first batch before the barrier that publishes the staging tile (see cv_epilogue). Written as load-then-use inside
+// the loop, each of them costs a full memory round trip (the compiler keeps `s_waitcnt vmcnt(0)` right behind every load: found
+// in the ISA), 8 x 3 serial round trips per workgroup in the data-gradient launches.
 // Column partials of a tile's statistics: over the lanes / wavefronts that share a channel chunk, in a fixed order -> stats[mt]
 template <int BN>
 __device__ __forceinline__ void cv_epilogue_stats(const ConvP& p, float (&ssum)[8], float (&ssq)[8], float* Ss, int t, int n0, int mt) {
@@ -202,14 +202,14 @@ __device__ __forceinline__ void cv_epilogue(const ConvP& p, const f32x16 (&acc)[
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
 
     constexpr int HALF = NIT / NBATCH;                          // rows per batch (NBATCH = 4: fewer registers, for the 4-per-CU variant)
-    // Every launch but the one with BOTH shortcut-gradient streams: the thread's rows in batches, software-pipelined — batch b + 1's operand loads are issued
-    // BEFORE batch b's arithmetic and stores — and free of control flow around the memory instructions: loads and stores are buffer
+    // Every launch but the one with BOTH shortcut-gradient streams: the thread's rows in batches, software-pipelined — batch b + 1's
+    // operand loads are issued BEFORE batch b's arithmetic and stores — and free of control flow around the memory instructions: loads and stores are buffer
     // instructions, the descriptor of an operand the launch does not have is EMPTY (out-of-range lanes read zeros / store nothing,
     // without a memory access) and the descriptors end at row M, which also drops the rows of a ragged tile. The wait counter is
     // in issue order, so the compiler can then wait for "everything but the newest N" and N covers the stores: nothing in the
     // epilogue waits for a store to be acknowledged. With a conditional store or load in between it has to assume the shortest
     // path and emits `s_waitcnt vmcnt(0)` — in the general loop below that is one store round trip per row, eight in a row per
-    // workgroup tile (found in the ISA; same-box A/B of the full-tile form: -0.13 ms per train step).
+    // workgroup tile (found in the ISA; same-box A/B: -0.19 ms per train step for the dense launches, -0.07 ms more for the scattered ones).
     if (!(p.addend && p.addend2)) {
         // y-shaped operands span the whole result tensor (the scattered rows of a stride-2 class launch index it like y itself)
         const uint32_t ybytes = p.o2 ? (uint32_t)p.N * (uint32_t)p.OH * (uint32_t)p.OW * (uint32_t)p.Cout * 2u : (uint32_t)p.M * (uint32_t)p.Cout * 2u;
