@@ -24,78 +24,9 @@
 // Workgroup ids are remapped so that the N-tiles of one M-tile run on the same XCD (A tile re-reads hit that L2).
 #include <cstdlib>
 #include "dir_common.h"
+#include "dir_conv_shared.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-struct ConvP {
-    const uint16_t* x; const uint16_t* w; uint16_t* y; float* stats;
-    const uint16_t* addend;   // optional [M][Cout] bf16 added to the rounded result (fused gradient accumulation)
-    const uint16_t* mask;     // optional [M][Cout] bf16: result zeroed where !(mask > 0) (fused ReLU backward)
-    const uint16_t* addend2;  // optional COMPACT addend [N][Ho/2][Wo/2][Cout] bf16, added at the even (ho, wo) only: the data
-                              // gradient of a 1x1 stride-2 convolution of the same input, never scattered to full size
-    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-    int M, KT, cpk, ntn, nblocks;
-    int simple;               // 1x1, stride 1, pad 0: row m of the GEMM is row m of x (no index arithmetic at all)
-    float inv_wo, inv_ho;     // reciprocals for the (n, ho, wo) decode of the general case
-    int o2, o_a, o_b, OH, OW; // o2: output row (n, i, j) is stored at pixel (2 i + o_a, 2 j + o_b) of an [N][OH][OW][Cout] tensor
-                              // (one parity class of a stride-2 data gradient); else rows are stored densely
-    int nbuf;                 // LDS stages of the K loop: 2 = prefetched tile written while the current one is read, 1 = extra barrier
-    // BatchNorm-backward reduction fused into a data-gradient store loop: this launch's result is the gradient of the OUTPUT of a
-    // BatchNorm whose input is bnx (same [rows][Cout] geometry as y); `stats` then receives the per-tile partials (sum g, sum g*bnx)
-    // of dir_bn_bwd's first pass. With bn_gamma: that BatchNorm is followed by a ReLU whose mask (bnx * a + b > 0, the forward's own
-    // decision) is applied to g for the sums only (the stored gradient stays unmasked: the BatchNorm's apply pass masks it again).
-    const uint8_t* mask_bits; // the same ReLU mask as one bit per element ([M][Cout / 8] bytes, dir_bn_*_bits), instead of `mask`
-    const uint16_t* bnx;
-    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_rstd;
-};
-struct ConvBn { const void* x; const float* gamma; const float* beta; const float* mean; const float* rstd; const void* mask_bits; };
-
-constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows
-constexpr int CV_DMA_MIN_KT = 32;                                // shortest K loop (64-wide steps) that takes the LDS-DMA variant: measured +3...+20 % from 32 steps up, mixed at 16, slower below (profiles/r02_conv_variants.txt)
-constexpr int CV_OOB = (int)0x80000000;                         // buffer-load offset beyond any tensor: the load returns zeros
-
-__device__ __forceinline__ uint32_t cv_f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) uint32_t cv_u32x4;
-// Cache policy `sc1 nt` of a buffer store (aux bits of the raw buffer intrinsics on gfx940+: 1 = sc0, 2 = nt, 16 = sc1). Kept as a
-// compiler-visible intrinsic: an inline-asm store hides its 128-bit data registers from the hazard recognizer (overwritten one
-// instruction later -> corrupted rows, found as NaNs in a BatchNorm's running variance).
-constexpr int CV_AUX_SC1_NT = 18;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-// two floats -> packed bf16x2 (round to nearest even, quiet NaN): one v_cvt_pk_bf16_f32 on gfx950
-__device__ __forceinline__ uint32_t cv_pack_bf16(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-// Accumulators -> bf16 -> LDS staging tile [128 pixels][CS_STRIDE]. The K loops feed the MFMA with the operands SWAPPED
-// (weights as the "A" matrix, pixels as "B"), so an accumulator tile is D'[channel][pixel]: lane l holds pixel (l & 31) and, in
-// registers 4 q .. 4 q + 3, the four CONSECUTIVE channels 8 q + 4 (l >> 5) + {0..3}. Two v_cvt_pk_bf16_f32 make them one 8-byte
-// ds_write_b64: 16 LDS stores per lane for a 64 x 64 wavefront tile instead of the 128 ds_write_b16 of the pixel-major
-// orientation, whose 2048 LDS cycles per workgroup tile (= four K-steps of MFMA time) were the whole cost of the 1-4 step
-// K loops of the 1x1 layers. Row stride 272 / 144 B: consecutive pixels shift 4 banks -> 2-way on the write, rows stay 16-B
-// aligned for the row reads of the store loop.
-template <int MI, int NI, int CS_STRIDE>
-__device__ __forceinline__ void cv_stage_acc(const f32x16 (&acc)[MI][NI], unsigned char* cbase) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t lo = cv_pack_bf16(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1]);
-                const uint32_t hi = cv_pack_bf16(acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
-                *reinterpret_cast<uint2*>(cbase + mi * 32 * CS_STRIDE + (ni * 32 + 8 * q) * 2) = make_uint2(lo, hi);
-            }
-}
 
 // Epilogue shared by the K-loop variants: accumulators -> bf16 staging tile in LDS (the K-loop buffers are free: the caller
 // has passed a barrier after its last fragment read) -> 16-B row stores with the fused statistics / addend / mask options.
@@ -836,19 +767,6 @@ template <int WI> struct CpGeom {
     static_assert(WI % RB == 0 && P % 16 == 0 && P >= WI + 2 && PROWS % 8 == 0, "chunk geometry");
 };
 
-typedef __attribute__((ext_vector_type(4))) uint32_t cp_u32x4;
-__device__ __forceinline__ cp_u32x4 cp_rsrc(const void* base, uint32_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base);
-    cp_u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-    return r;
-}
-__device__ __forceinline__ void cp_dma16(cp_u32x4 rs, uint32_t lds_addr, int voffset, int soffset) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
-}
-__device__ __forceinline__ void cp_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // NST = 2: two patch stages (Cin > 64) and two weight stages, the next slice in flight under the MFMAs: 56-80 KB of LDS, two
 // workgroups per CU. NST = 1: one stage each (<= 40 KB, <= 128 registers): FOUR workgroups per CU, no overlap inside a workgroup.
 template <int WI, int BN, int NST>
@@ -1056,6 +974,12 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                        float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        dir_stream_t stream);
+// A/B switch for tools and tests (process-wide, default 0 — see DESIGN.md for the measurements): 1 = the 128-wide launches that are not patch-staged take the persistent
+// ring kernel (dir_conv_ring.hip), 0 = the one-tile-per-workgroup kernels of this file. Same tiling of M either way (128 rows:
+// the `stats` list does not change). Returns the previous setting.
+static int g_ring = 0;
+static int g_ring_dbg = 0;    // measurement builds only: bit 0 = no fragment reads / MFMA, bit 1 = no LDS-DMA (mode = 1 | dbg << 4)
+extern "C" int dir_conv_set_ring(int mode) { const int prev = g_ring | (g_ring_dbg << 4); g_ring = (mode & 15) ? 1 : 0; g_ring_dbg = mode >> 4; return prev; }
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
                           float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn = nullptr);
@@ -1080,7 +1004,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 // 1 = register-staged, 2 = LDS-DMA, 3 = patch-staged 3x3; 1 and 2 tile M by 128 rows: stats rows = dir_conv_stats_rows).
 extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                                     int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
-    DIR_RETURN_IF(variant < 0 || variant > 3, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > 4, DIR_EINVAL);
     DIR_RETURN_IF(variant == 3 && !(R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)), DIR_EUNSUPPORTED);
     return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
@@ -1202,7 +1126,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int tile_n = wide ? 128 : 64;
     const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
-    const int cpw = (cls || variant == 1 || variant == 2) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
+    const int cpw = (cls || variant == 1 || variant == 2 || variant == 4) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
     if (cpw) {
         // patch-staged 3x3: M tiles = chunks of whole image rows
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
@@ -1225,6 +1149,14 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
 #undef CP_LAUNCH
         DIR_LAUNCH_CHECK();
         return DIR_OK;
+    }
+    if (variant == 4 || (variant == 0 && g_ring)) {
+        // persistent ring kernel (8 wavefronts, loader / storer roles, ring of LDS-DMA stages across tile boundaries)
+        if (conv_ring_takes(p)) {
+            const int rc = conv_ring_launch(p, g_ring_dbg, s);
+            return rc == 0 ? DIR_OK : rc;
+        }
+        DIR_RETURN_IF(variant == 4, DIR_EUNSUPPORTED);
     }
     const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
     if (dma) {

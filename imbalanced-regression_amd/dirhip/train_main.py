@@ -336,7 +336,8 @@ def run(argv=None, dataset_default='imdb_wiki'):
         checkpoint = torch.load(args.resume, map_location=device)
         model.load_state_dict(checkpoint['state_dict'], strict=False)
         print(f"===> Checkpoint '{args.resume}' loaded (epoch [{checkpoint['epoch']}]), testing...")
-        validate(eval_batches(test_set), n_val, model, args, train_labels=train_labels, prefix='Test')
+        n_test = (len(test_set) + args.batch_size - 1) // args.batch_size
+        validate(eval_batches(test_set), n_test, model, args, train_labels=train_labels, prefix='Test')
         return
 
     if args.retrain_fc:
@@ -398,6 +399,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
     checkpoint = torch.load(f"{args.store_root}/{args.store_name}/ckpt.best.pth.tar", map_location=device)
     model.load_state_dict(checkpoint['state_dict'])
     print(f"Loaded best model, epoch {checkpoint['epoch']}, best val loss {checkpoint['best_loss']:.4f}")
-    test_loss_mse, test_loss_l1, test_loss_gmean = validate(eval_batches(test_set), n_val, model, args,
+    n_test = (len(test_set) + args.batch_size - 1) // args.batch_size
+    test_loss_mse, test_loss_l1, test_loss_gmean = validate(eval_batches(test_set), n_test, model, args,
                                                             train_labels=train_labels, prefix='Test')
     print(f"Test loss: MSE [{test_loss_mse:.4f}], L1 [{test_loss_l1:.4f}], G-Mean [{test_loss_gmean:.4f}]\nDone")

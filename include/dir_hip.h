@@ -277,6 +277,10 @@ size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad
  * dir_conv_tile_rows answers accordingly), 1 = patch-staged with one LDS stage (four workgroups per CU), 2 = patch-staged with
  * two stages (two per CU).  Returns the previous setting; flip only between whole passes. */
 int dir_conv_set_patch3x3(int mode);
+/* A/B switch for tools and tests (process-wide, default 0): 1 = launches with Cout % 128 == 0 that are not patch-staged run the
+ * persistent ring kernel (csrc/dir_conv_ring.hip: 8 wavefronts per CU with loader / storer roles, LDS-DMA ring across tile
+ * boundaries), 0 = the one-tile-per-workgroup kernels.  Same results bit for bit, same `stats` rows.  Returns the previous setting. */
+int dir_conv_set_ring(int mode);
 /* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
@@ -353,7 +357,7 @@ size_t dir_stem_conv_wgrad_workspace(int N, int H);
 int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, void* workspace,
                         size_t workspace_bytes, dir_stream_t stream);
 
-/* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd,
+/* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd, 4 = the persistent ring kernel (DIR_EUNSUPPORTED when the geometry is not taken),
  * 1 = register-staged loop (global -> VGPR -> ds_write), 2 = LDS-DMA loop (buffer_load ... lds, two stages). */
 int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                          int R, int S, int stride, int pad, int variant, dir_stream_t stream);

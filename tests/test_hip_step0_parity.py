@@ -278,31 +278,206 @@ def test_bf16_fused_wiring_vs_plain_composition_per_chain(name):
         assert res["y"] <= 1e-2 and res["dx"] <= 3e-2 and res["param_grad_max"] <= 3e-2, res
 
 
+def _vs_emulation(model, loss, pred, enc, e, cols=None):
+    """bf16 product path against the reference run with bf16 rounding emulated at the product's store points (float64 arithmetic
+    in between: tests/golden/gen_golden_r3.py). What is left between the two is accumulation-order noise that flips individual
+    bf16 roundings, amplified through the depth of the network — two orders of magnitude below the bf16-vs-float32 gap."""
+    res = {}
+    el = float(e["emul_loss"])
+    res["loss"] = float(loss.item())
+    res["loss_rel_err"] = abs(res["loss"] - el) / el
+    res["pred_rel_l2"] = _rel(pred.detach().double().cpu().numpy(), e["emul_pred"].astype(np.float64))
+    en = enc.detach().double().cpu().numpy()
+    if cols is None:
+        res["encoding_rel_l2"] = _rel(en, e["emul_encoding"].astype(np.float64))
+    else:
+        res["encoding_rel_l2"] = _rel(en[:, cols], e["emul_encoding_cols"].astype(np.float64))
+        res["encoding_rowsum_rel_l2"] = _rel(en.sum(1), e["emul_encoding_rowsum"])
+    lw = model.linear.weight.grad.detach().double().cpu().numpy()
+    res["linear_weight_grad_rel_l2"] = _rel(lw, e["emul_linear_weight_grad"])
+    res["linear_bias_grad_rel"] = float(abs(model.linear.bias.grad.item() - float(e["emul_linear_bias_grad"][0])) / abs(float(e["emul_linear_bias_grad"][0])))
+    rows = []
+    for i, (n, got, norm, k) in enumerate(_sampled(model, e)):
+        rows.append((n, _rel(got, e["emul_grad_samples"][i][:k]), norm / float(e["emul_grad_norms"][i])))
+    res["grad_rel_l2_median"] = float(np.median([r[1] for r in rows]))
+    res["grad_norm_ratio_min_max"] = [float(min(r[2] for r in rows)), float(max(r[2] for r in rows))]
+    res["grad_layer4_last_block"] = [r for r in rows if r[0].startswith("layer4.2")]
+    return res, rows
+
+
 def test_bf16_product_path_step_vs_reference(golden):
+    """B = 64. (1) against the reference's float32 run: the bf16-vs-float32 gap itself (loss 3e-4, encoding 11 %; bars kept as a
+    sanity ceiling). (2) THE bf16 parity bar: against the reference run with bf16 rounding emulated at the product path's
+    store points (step0_b64_bf16emul.npz) — loss, predictions, encoding, BatchNorm running statistics and the gradients of the
+    layers next to the loss at rounding-flip noise."""
     g = golden("step0_b64.npz")
+    e = golden("step0_b64_bf16emul.npz")
     _, model, loss, pred, enc, _ = _run_step(g, torch.bfloat16)
     res = {}
     ref_loss = float(g["ref_loss"])
     res["loss"] = float(loss.item())
     res["loss_rel_err_vs_reference"] = abs(res["loss"] - ref_loss) / ref_loss
     res["encoding_rel_l2_vs_reference"] = _rel(enc.detach().float().cpu().numpy().astype(np.float64), g["ref_encoding"].astype(np.float64))
-    res["pred_rel_l2_vs_reference"] = _rel(pred.detach().float().cpu().numpy().astype(np.float64), g["ref_pred"].astype(np.float64))
+    res["emulated_reference_vs_reference_encoding_rel_l2"] = _rel(e["emul_encoding"].astype(np.float64), g["ref_encoding"].astype(np.float64))
+    em, rows = _vs_emulation(model, loss, pred, enc, e)
+    res["vs_bf16_emulated_reference"] = em
+    for k, (a, b) in {"bn1_running_mean": (model.bn1.running_mean, e["emul_bn1_running_mean"]), "bn1_running_var": (model.bn1.running_var, e["emul_bn1_running_var"]),
+                      "layer4.2.bn3.running_var": (model.layer4[2].bn3.running_var, e["emul_l4_bn3_running_var"])}.items():
+        em[f"{k}_max_rel"] = float(np.max(np.abs(a.double().cpu().numpy() - b) / (np.abs(b) + 1e-6 * np.abs(b).max())))
+    fl = _emulation_noise_floor(e)
+    res["emulation_float32_vs_float64_arithmetic"] = fl
+    _RESULTS["bf16_product_path_vs_reference"] = res
+    _dump()
+    assert res["loss_rel_err_vs_reference"] <= 2e-3 and res["encoding_rel_l2_vs_reference"] <= 0.2, res       # sanity ceiling (bf16 vs float32)
+    _assert_at_noise_floor(em, fl)
+    assert em["bn1_running_var_max_rel"] <= 1e-5 and em["layer4.2.bn3.running_var_max_rel"] <= 1.5 * fl["layer4.2.bn3.running_var_max_rel"] + 1e-4, (em, fl)
+
+
+def _emulation_noise_floor(e, cols=False):
+    """The SAME bf16-rounded graph evaluated twice by the reference's modules, with float64 and with float32 arithmetic between
+    the rounding points (golden): what two correct evaluations of this bf16 network differ by. A bf16 rounding turns a relative
+    difference d << 2^-8 into sqrt(d * 2^-8), so any accumulation-order difference grows to the bf16 ulp within a few layers
+    and the depth of the random-init network amplifies it further: whole-network agreement of two bf16 evaluations stops at a
+    few percent, whatever kernels compute them. The sharp bf16 check is per block on identical inputs (teacher-forced test)."""
+    fl = {"loss_rel_err": abs(float(e["emul32_loss"]) - float(e["emul_loss"])) / float(e["emul_loss"]),
+          "pred_rel_l2": _rel(e["emul32_pred"].astype(np.float64), e["emul_pred"].astype(np.float64)),
+          "linear_weight_grad_rel_l2": _rel(e["emul32_linear_weight_grad"].astype(np.float64), e["emul_linear_weight_grad"])}
+    if cols:
+        fl["encoding_rel_l2"] = _rel(e["emul32_encoding_cols"].astype(np.float64), e["emul_encoding_cols"].astype(np.float64))
+    else:
+        fl["encoding_rel_l2"] = _rel(e["emul32_encoding"].astype(np.float64), e["emul_encoding"].astype(np.float64))
+        a, b = e["emul32_l4_bn3_running_var"].astype(np.float64), e["emul_l4_bn3_running_var"].astype(np.float64)
+        fl["layer4.2.bn3.running_var_max_rel"] = float(np.max(np.abs(a - b) / (np.abs(b) + 1e-6 * np.abs(b).max())))
+    return fl
+
+
+def _assert_at_noise_floor(em, fl):
+    """The product's bf16 kernels vs the float64-arithmetic emulation: no further from it than the float32-arithmetic
+    emulation is (x1.5), quantity by quantity."""
+    for k in ("pred_rel_l2", "encoding_rel_l2", "linear_weight_grad_rel_l2"):
+        assert em[k] <= 1.5 * fl[k] + 1e-4, (k, em[k], fl[k])
+    assert em["loss_rel_err"] <= 1.5 * fl["loss_rel_err"] + 2e-4, (em["loss_rel_err"], fl["loss_rel_err"])
+    assert em["linear_bias_grad_rel"] <= 1e-5, em
+    assert 0.8 <= em["grad_norm_ratio_min_max"][0] and em["grad_norm_ratio_min_max"][1] <= 1.25, em
+
+
+def test_float32_mode_step_matches_reference_golden_B256(golden):
+    """BASELINE configs[1]'s own batch size: one float32-mode step at B = 256 against the reference's float32 / float64 runs."""
+    g = golden("step0_b256.npz")
+    cfg, model, loss, pred, enc, _ = _run_step(g, None)
+    cols = g["encoding_cols"]
+    res = {}
+    ref_loss = float(g["ref_loss"])
+    res["loss"] = float(loss.item())
+    res["loss_rel_err"] = abs(res["loss"] - ref_loss) / ref_loss
+    res["pred_rel_l2"] = _rel(pred.detach().double().cpu().numpy(), g["ref_pred"].astype(np.float64))
+    en = enc.detach().double().cpu().numpy()
+    res["encoding_rel_l2"] = _rel(en[:, cols], g["ref_encoding_cols"].astype(np.float64))
+    res["encoding_rel_l2_vs_float64_reference"] = _rel(en[:, cols], g["ref64_encoding_cols"].astype(np.float64))
+    res["encoding_rowsum_rel_l2"] = _rel(en.sum(1), g["ref_encoding_rowsum"])
+    res["reference_float32_vs_float64_encoding_rel_l2"] = float(g["ref32_vs_ref64_encoding_rel_l2"])
     rows = []
     for i, (n, got, norm, k) in enumerate(_sampled(model, g)):
         r64 = g["ref64_grad_samples"][i][:k]
-        rows.append((n, _rel(got, r64), norm / float(g["ref64_grad_norms"][i])))
-    res["grad_rel_l2_vs_float64_reference_median"] = float(np.median([r[1] for r in rows]))
-    res["grad_norm_ratio_min_max"] = [float(min(r[2] for r in rows)), float(max(r[2] for r in rows))]
-    res["grad_tail_layers"] = [r for r in rows if r[0].startswith(("linear", "layer4.2"))]
-    _RESULTS["bf16_product_path_vs_reference"] = res
+        r32 = g["ref_grad_samples"][i][:k].astype(np.float64)
+        rows.append((n, _rel(got, r64), _rel(r32, r64), abs(norm - float(g["ref64_grad_norms"][i])) / float(g["ref64_grad_norms"][i])))
+    ours, theirs = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    res["grad_rel_l2_vs_float64_reference_median"] = float(np.median(ours))
+    res["reference_float32_grad_rel_l2_vs_float64_median"] = float(np.median(theirs))
+    res["grad_ratio_ours_over_reference_max"] = float(np.max(ours / np.maximum(theirs, 1e-6)))
+    res["grad_norm_rel_err_max"] = float(max(r[3] for r in rows))
+    for k, (a, b) in {"bn1_running_var": (model.bn1.running_var, g["ref_bn1_running_var"]),
+                      "layer4.2.bn3.running_var": (model.layer4[2].bn3.running_var, g["ref_l4_bn3_running_var"])}.items():
+        res[f"{k}_max_rel"] = float(np.max(np.abs(a.cpu().numpy() - b) / (np.abs(b) + 1e-6 * np.abs(b).max())))
+    # a batch MEAN over 256 x 112^2 zero-centred samples is a cancellation: its error is measured against the channel's standard deviation
+    a, b = model.bn1.running_mean.cpu().numpy().astype(np.float64), g["ref_bn1_running_mean"].astype(np.float64)
+    res["bn1_running_mean_max_rel"] = float(np.max(np.abs(a - b) / (np.abs(b) + 0.1 * np.sqrt(g["ref_bn1_running_var"].astype(np.float64)))))
+    _RESULTS["float32_mode_vs_reference_B256"] = res
     _dump()
-    # measured bf16 tolerances (see module docstring; DESIGN.md quotes gpurun_out/parity_step0.json)
-    assert res["loss_rel_err_vs_reference"] <= 2e-3, res
-    assert res["encoding_rel_l2_vs_reference"] <= 0.2 and res["pred_rel_l2_vs_reference"] <= 1.0, res
-    # the layers next to the loss see the least accumulated mask-flip noise: their gradients must match the reference
-    lin = {r[0]: r for r in rows}
-    assert lin["linear.bias"][1] <= 1e-5 and lin["linear.weight"][1] <= 0.2, (lin["linear.bias"], lin["linear.weight"])
-    assert 0.5 <= res["grad_norm_ratio_min_max"][0] and res["grad_norm_ratio_min_max"][1] <= 2.0, res
+    assert res["loss_rel_err"] <= 1e-5, res                                            # north_star: training loss within 1e-5 relative
+    assert res["pred_rel_l2"] <= 1e-4 and res["encoding_rel_l2"] <= 5e-5 and res["encoding_rowsum_rel_l2"] <= 1e-5, res
+    assert res["encoding_rel_l2_vs_float64_reference"] <= 1.5 * res["reference_float32_vs_float64_encoding_rel_l2"] + 1e-6, res
+    assert np.all(ours <= 1.5 * theirs + 1e-4), sorted(((r[0], r[1], r[2]) for r in rows), key=lambda r: -r[1] / max(r[2], 1e-6))[:5]
+    assert res["grad_norm_rel_err_max"] <= 2e-2, res
+    for k in ("bn1_running_mean", "bn1_running_var", "layer4.2.bn3.running_var"):
+        assert res[f"{k}_max_rel"] <= 1e-5, (k, res)
+
+
+def test_bf16_product_path_B256_vs_bf16_emulated_reference(golden):
+    """The benchmarked configuration itself (B = 256, bf16 product kernels) against the bf16-rounding-emulated reference run."""
+    g = golden("step0_b256.npz")
+    _, model, loss, pred, enc, _ = _run_step(g, torch.bfloat16)
+    em, rows = _vs_emulation(model, loss, pred, enc, g, cols=g["encoding_cols"])
+    em["loss_rel_err_vs_float32_reference"] = abs(float(loss.item()) - float(g["ref_loss"])) / float(g["ref_loss"])
+    fl = _emulation_noise_floor(g, cols=True)
+    em["emulation_float32_vs_float64_arithmetic"] = fl
+    _RESULTS["bf16_product_path_B256_vs_bf16_emulated_reference"] = em
+    _dump()
+    assert em["loss_rel_err_vs_float32_reference"] <= 2e-3, em
+    _assert_at_noise_floor(em, fl)
+
+
+def test_bf16_blocks_teacher_forced_vs_bf16_emulation():
+    """The sharp bf16 parity check of the forward arithmetic: every bottleneck block and the stem of the bf16 PRODUCT path
+    against the bf16-rounding emulation of the reference architecture (oracle.torch_oracle's port with oracle.bf16_emul's
+    rounding points, float64 arithmetic) ON THE PRODUCT'S OWN INPUT of that block — so accumulation-order noise cannot
+    compound over the depth. What is left is one block's worth of flipped bf16 roundings (three convolutions + the join)."""
+    from dirhip import resnet as R
+    from dirhip.parallel import DataParallelEngine
+    from oracle.bf16_emul import RoundBF16, bf16_points
+    from oracle.torch_oracle import _Bottleneck
+    import torch.nn.functional as F
+    torch.manual_seed(77)
+    model = R.resnet50(fds=False, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5,
+                       sigma=2, momentum=0.9).cuda()
+    with torch.no_grad():                                  # non-trivial BatchNorm affine parameters
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    eng = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
+    eng.train()
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(78))
+    caps, hooks = {}, []
+    for name, m in model.named_modules():
+        if isinstance(m, R.Bottleneck):
+            hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: caps.__setitem__(name, (i[0].detach().float().cpu(), o.detach().float().cpu()))))
+    eng(x.cuda())
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    res = {}
+    # ---- stem: conv 7x7/2 -> round -> BatchNorm (batch statistics of the rounded outputs) -> ReLU -> max pool -> round
+    w = model.conv1.weight.detach().cpu().bfloat16().double()
+    y = RoundBF16.apply(F.conv2d(x.bfloat16().double(), w, stride=2, padding=3))
+    y = F.batch_norm(y, None, None, model.bn1.weight.detach().cpu().double(), model.bn1.bias.detach().cpu().double(), True, 0.0, model.bn1.eps)
+    y = RoundBF16.apply(F.max_pool2d(torch.relu(y), 3, 2, 1))
+    got = caps["layer1.0"][0].double()
+    res["stem"] = {"rel_l2": _rel(got.numpy(), y.numpy()), "max_abs": float((got - y).abs().max()), "out_max": float(y.abs().max())}
+    # ---- blocks, each on the product's own input
+    for name, (xin, yout) in caps.items():
+        blk = dict(model.named_modules())[name]
+        ds = None
+        if blk.downsample is not None:
+            c = blk.downsample[0]
+            ds = torch.nn.Sequential(torch.nn.Conv2d(c.in_channels, c.out_channels, 1, c.stride, bias=False), torch.nn.BatchNorm2d(c.out_channels))
+        ob = _Bottleneck(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv2.stride[0], ds)
+        ob.load_state_dict({k: v.detach().cpu() for k, v in blk.state_dict().items()})
+        ob = ob.double()
+        bf16_points(ob)
+        ob.train()
+        with torch.no_grad():
+            ye = ob(xin.double())
+        d = (yout.double() - ye)
+        res[name] = {"rel_l2": float(d.norm() / ye.norm()), "max_abs": float(d.abs().max()), "out_max": float(ye.abs().max()),
+                     "fraction_differing": float((d != 0).double().mean())}
+    _RESULTS["bf16_blocks_teacher_forced_vs_bf16_emulation"] = res
+    _dump()
+    # measured (profiles/r03_parity_step0.json): stem 1.1e-5, blocks 1.8e-4 ... 1.3e-3 with every differing element exactly one bf16
+    # ulp away (0.2 - 8 % of the elements: roundings that sit on a tie within the accumulation-order noise)
+    assert res["stem"]["rel_l2"] <= 1e-4, res["stem"]
+    for name, r in res.items():
+        assert r["rel_l2"] <= 3e-3 and r["max_abs"] <= r["out_max"] * 2.0 ** -7, (name, r)
 
 
 def test_whole_model_forward_vs_reference_golden_B2(golden):
