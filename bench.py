@@ -149,6 +149,43 @@ def timed(fn, device, world):
     return dt, out
 
 
+def comm_probe(engine, optimizer, batches, loss_fn, epoch, device, world):
+    """N > 1 observability (rank 0 prints it): ranks and backend, the gradient buckets, each bucket's all-reduce alone (ms and bus
+    bandwidth 2 (N - 1) / N x bytes / time — the figure to hold against one xGMI link), and the communication a training step does
+    NOT hide behind its backward pass (HIP events on the compute stream: last backward kernel -> last collective done)."""
+    from dirhip.train_loop import train_step
+    engine.measure_comm = True
+    exposed = []
+    for i in range(4):
+        train_step(engine, optimizer, *batches[i % len(batches)], epoch, loss_fn)
+        exposed.append(engine.comm_report().get("exposed_comm_ms_last_step"))
+    engine.measure_comm = False
+    rep = engine.comm_report()
+    rows = []
+    for b in engine._buckets:
+        t = torch.zeros_like(b.flat)
+        for _ in range(2):
+            dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        iters = 5
+        for _ in range(iters):
+            dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / iters
+        nbytes = t.numel() * 4
+        rows.append({"MB": round(nbytes / 2 ** 20, 2), "allreduce_ms": dt * 1e3, "bus_GBs": 2.0 * (world - 1) / world * nbytes / dt / 1e9})
+        del t
+    vals = [v for v in exposed[1:] if v is not None]
+    return {"rccl_ranks": rep["ranks"], "backend": rep["backend"], "reduce_op": rep["reduce_op"], "buckets": rows,
+            "allreduce_ms_per_step_if_serial": sum(r["allreduce_ms"] for r in rows),
+            "exposed_comm_ms_per_step": (sum(vals) / len(vals)) if vals else None,
+            "grad_copies_per_step": rep["grad_copies"] / max(1, rep["steps"]), "bucket_scale_kernels": rep["bucket_scale_kernels"],
+            "note": "exposed = compute-stream time between the last backward kernel and the completion of the last bucket's all-reduce; "
+                    "the per-bucket rows are isolated collectives (no overlap with compute)"}
+
+
 def event_time_ms(fn, iters, warm=3):
     """Average duration of fn(i) over `iters` launches with HIP events on torch's current stream
     (= the stream the C-ABI launches on)."""
@@ -493,6 +530,8 @@ def main():
                           "train_only_frac": args.steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / PEAK_BF16_TFLOPS},
     }
     result["roofline"] = dict(result["roofline_loop"], traffic=None)      # replaced below by the dominant kernel's when measured
+    if world > 1:
+        result["comm"] = comm_probe(engine, optimizer, batches, loss_fn, epoch, device, world)
     if rank == 0 and world == 1 and not args.no_kernel_rooflines:
         fam = in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch)
         log("in-situ kernel breakdown done")

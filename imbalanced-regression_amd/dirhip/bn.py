@@ -15,6 +15,7 @@ for ``running_var``, ``momentum`` blend, ``num_batches_tracked += 1``).
 import torch
 
 from . import _lib as L
+from . import gradsink
 
 _DT = {torch.bfloat16: L.DIR_BF16, torch.float32: L.DIR_F32}
 
@@ -119,8 +120,8 @@ class _BNActFn(torch.autograd.Function):
             dres = None
         else:
             dres = torch.empty_like(x) if ctx.has_res else None
-        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        dgamma = gradsink.out_for(gamma, (c,), x.device)     # (the data-parallel engine's bucket slot when there is one)
+        dbeta = gradsink.out_for(beta, (c,), x.device)
         ws = _ws(code, m, c, x.device)
         link = getattr(ctx, "link", None)
         part = None if link is None else link.partial
@@ -190,7 +191,7 @@ class _BNJoinFn(torch.autograd.Function):
         stream = L.stream_ptr(dev)
         f32 = torch.float32
         dx, dr = torch.empty_like(x), torch.empty_like(r)
-        dgamma, dbeta, dgamma_r, dbeta_r = (torch.empty(c, dtype=f32, device=dev) for _ in range(4))
+        dgamma, dbeta, dgamma_r, dbeta_r = (gradsink.out_for(t, (c,), dev) for t in (gamma, beta, gamma_r, beta_r))
         link = ctx.deferred
         if (not ctx.relu or (link is not None and link[0])) and _JOIN_BWD[0]:
             # no ReLU, or its backward was applied by the consumer (bn_act doc): dout is the gradient of both BatchNorms as it stands —

@@ -11,6 +11,7 @@ of all layers are re-made by one launch per optimizer step.
 import torch
 
 from . import _lib as L
+from . import gradsink
 
 
 def supported(cin, cout, x=None):
@@ -104,8 +105,9 @@ def set_wgrad3_all_taps(enabled):
     return prev
 
 
-def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
-    """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``."""
+def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None):
+    """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``. ``sink``: the
+    parameter's gradient-bucket factory (``gradsink.lookup``): the kernel then writes into the data-parallel bucket."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
     if not dy.is_contiguous(memory_format=torch.channels_last):
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -114,7 +116,7 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     r = s = kernel_size
-    dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    dw = gradsink.out_for(sink, (cout, cin, r, s), x.device, torch.channels_last)
     if kernel_size == 3 and stride == 1 and padding == 1 and _WGRAD3_ALL_TAPS[0]:
         nbytes = L.lib().dir_conv_wgrad3x3_workspace(n, h, w, cin, cout)
         if nbytes:
@@ -141,6 +143,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, w16, w16_rot, stride, padding, want_stats, alias_input, relu_input, bn_link=None, relu_bits=None):
         ctx.stride, ctx.padding = stride, padding
+        ctx.wsink = gradsink.lookup(weight)
         ctx.alias_input = alias_input
         ctx.bn_link = bn_link                    # bn.BwdLink of the BatchNorm that produced x (its backward reduction is ours)
         ctx.relu_bits = relu_bits if relu_input else None      # x > 0 as one bit per element (bn._relu_bits_for), if the forward made it
@@ -184,7 +187,7 @@ class _ConvFn(torch.autograd.Function):
                               relu_mask=x if (ctx.relu_input and bits is None) else None, bn_link=link, relu_bits=bits)
             dalias = None
             need_dx = False
-        dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding)          # float32, deterministic split-K
+        dw = conv2d_wgrad(dy, x, w16.shape[2], ctx.stride, ctx.padding, sink=ctx.wsink)   # float32, deterministic split-K
         if need_dx and w16_rot is not None and w16_rot.dim() == 1 and ctx.stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             # 3x3 / stride 2 / pad 1: four stride-1 launches, one per output-pixel parity class (dir_conv_dgrad_s2)
             n_, cin_, h_, w_ = x.shape
@@ -222,6 +225,7 @@ class _ProjectionPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w1_16, w1_rot, wd, wd_16, wd_rot, stride_d, want_stats, relu_input, bn_link=None, relu_bits=None):
         ctx.set_materialize_grads(False)
+        ctx.wsinks = (gradsink.lookup(w1), gradsink.lookup(wd))
         ctx.stride_d, ctx.relu_input = stride_d, relu_input
         ctx.bn_link = bn_link
         ctx.relu_bits = relu_bits if relu_input else None
@@ -258,8 +262,8 @@ class _ProjectionPairFn(torch.autograd.Function):
             dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend=compact, relu_mask=mask, bn_link=link, relu_bits=bits)
         else:
             dx = conv2d_igemm(dy1, w1_rot, 1, 0, addend_s2=compact, relu_mask=mask, bn_link=link, relu_bits=bits)
-        dw1 = conv2d_wgrad(dy1, x, 1, 1, 0)
-        dwd = conv2d_wgrad(dyd, x, 1, ctx.stride_d, 0) if dyd is not None else None
+        dw1 = conv2d_wgrad(dy1, x, 1, 1, 0, sink=ctx.wsinks[0])
+        dwd = conv2d_wgrad(dyd, x, 1, ctx.stride_d, 0, sink=ctx.wsinks[1]) if dyd is not None else None
         return dx if ctx.needs_input_grad[0] else None, dw1, None, None, dwd, None, None, None, None, None, None, None
 
 
@@ -466,7 +470,7 @@ class _StemConvFn(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy = dy.contiguous(memory_format=torch.channels_last)
         n, _, h, w = x16.shape
-        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x16.device, memory_format=torch.channels_last)
+        dw = gradsink.out_for(weight, (64, 3, 7, 7), x16.device, torch.channels_last)
         ws = torch.empty(L.lib().dir_stem_conv_wgrad_workspace(n, h), dtype=torch.uint8, device=x16.device)
         L.check(L.lib().dir_stem_conv_wgrad(L.ptr(dy), L.ptr(x16), L.ptr(dw), n, h, w, L.ptr(ws), ws.numel(),
                                             L.stream_ptr(x16.device)), "dir_stem_conv_wgrad")

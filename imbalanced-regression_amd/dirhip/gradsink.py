@@ -1,0 +1,40 @@
+"""Where a parameter's gradient is WRITTEN. ``parallel.DataParallelEngine`` keeps every gradient in a few flat float32
+buckets (one RCCL all-reduce each); instead of letting the backward kernels write freshly allocated tensors that a hook
+then copies into the bucket (161 copy kernels per step), the engine registers, per parameter, a factory of views into the
+parameter's slot of its bucket, and the gradient-producing nodes (weight gradients of the convolutions, BatchNorm
+dgamma / dbeta, the tail's linear layer) allocate their outputs through ``out_for``: the kernels write straight into the
+bucket. Every call hands out a FRESH view object, so autograd's AccumulateGrad takes it over as ``param.grad`` without a copy.
+Single process (no engine buckets): ``out_for`` is ``torch.empty``.
+"""
+import torch
+
+_SINKS = {}                       # parameter storage address -> zero-argument callable returning a fresh view of its bucket slot
+
+
+def register(param, factory):
+    _SINKS[param.data_ptr()] = factory
+
+
+def unregister(params):
+    for p in params:
+        _SINKS.pop(p.data_ptr(), None)
+
+
+def lookup(param):
+    """The factory for ``param`` (any tensor object that shares the parameter's storage address), or None."""
+    return _SINKS.get(param.data_ptr()) if _SINKS else None
+
+
+def out_for(param_or_factory, shape, device, memory_format=torch.contiguous_format):
+    """Float32 output tensor of ``shape`` for the gradient of ``param``: its bucket slot when an engine registered one (and the
+    geometry matches), else a new tensor."""
+    f = param_or_factory if (param_or_factory is None or callable(param_or_factory)) else lookup(param_or_factory)
+    if f is not None:
+        v = f()
+        if v is not None and v.device == device:
+            if tuple(v.shape) == tuple(shape):
+                if memory_format == torch.contiguous_format or v.is_contiguous(memory_format=memory_format):
+                    return v
+            elif v.numel() == int(torch.Size(shape).numel()) and v.is_contiguous():
+                return v.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=memory_format)

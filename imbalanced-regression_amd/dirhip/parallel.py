@@ -24,6 +24,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import gradsink
+
 
 def init_distributed(backend=None):
     """Initialise the default process group from torchrun's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
@@ -45,23 +47,35 @@ def init_distributed(backend=None):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work")
+    __slots__ = ("flat", "params", "views", "offsets", "dense", "pending", "work", "ev0", "ev1")
+
+    ALIGN = 64                          # elements: every slot starts on a 256-byte boundary (the gradient kernels store 16-byte vectors)
 
     def __init__(self, params, device):
-        n = sum(p.numel() for p in params)
+        n = sum((p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN for p in params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.params = params
-        self.views = []
+        self.views, self.offsets, self.dense = [], [], []
         off = 0
         for p in params:
             # same memory layout as the parameter (e.g. channels_last conv weights): fused / multi-tensor optimizer
             # kernels walk parameter and gradient storage with one linear index, so the layouts must agree
-            seg = self.flat[off:off + p.numel()]
             dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) if p.dim() == 4 else p.is_contiguous()
-            self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
-            off += p.numel()
+            self.offsets.append(off)
+            self.dense.append(bool(dense))
+            self.views.append(self.fresh_view(len(self.offsets) - 1))
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.pending = len(params)
         self.work = None
+        self.ev0 = self.ev1 = None
+
+    def fresh_view(self, pi):
+        """A NEW tensor object over parameter pi's slot (shape and strides of the parameter). The gradient kernels write into it
+        (``gradsink``) and autograd's AccumulateGrad adopts it as ``param.grad`` without a copy — which it only does for a tensor
+        nobody else references, hence a new object per call."""
+        p = self.params[pi]
+        seg = self.flat[self.offsets[pi]:self.offsets[pi] + p.numel()]
+        return seg.as_strided(p.shape, p.stride()) if self.dense[pi] else seg.view_as(p)
 
 
 class DataParallelEngine(nn.Module):
@@ -82,6 +96,12 @@ class DataParallelEngine(nn.Module):
         self._signature = None
         self._hooks = []
         self._callback_queued = False
+        # counters of avoidable per-step work (tests assert they stay 0 on the product graph) and communication timing
+        self.stats = {"grad_copies": 0, "bucket_scale_kernels": 0, "steps": 0, "exposed_comm_ms": 0.0}
+        self.measure_comm = False                       # bench.py: HIP events around the tail of the backward pass
+        # mean over ranks: RCCL reduces with AVG itself; other backends (gloo: tests) get gradients pre-scaled by 1 / world at the
+        # network's output (one [B, 1] kernel; exact for power-of-two world sizes) — never a pass over the 94 MB of buckets
+        self._native_avg = bool(self.world > 1 and dist.get_backend(process_group) == "nccl")
         if channels_last:
             self.module.to(memory_format=torch.channels_last)
         if self.world > 1 and broadcast_from_rank0:
@@ -101,8 +121,15 @@ class DataParallelEngine(nn.Module):
             inputs = inputs.contiguous(memory_format=torch.channels_last)
         if self.amp_dtype is not None:
             with torch.autocast(device_type=inputs.device.type, dtype=self.amp_dtype):
-                return self.module(inputs, *args, **kwargs)
-        return self.module(inputs, *args, **kwargs)
+                out = self.module(inputs, *args, **kwargs)
+        else:
+            out = self.module(inputs, *args, **kwargs)
+        if self.world > 1 and not self._native_avg and self.training and torch.is_grad_enabled():
+            inv = 1.0 / self.world
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.requires_grad:
+                    t.register_hook(lambda g, inv=inv: None if g is None else g * inv)        # (the prediction [B, 1]: every parameter gradient flows through it)
+        return out
 
     # ---- gradient buckets -------------------------------------------------------------------------
     def _prepare_buckets(self):
@@ -111,6 +138,8 @@ class DataParallelEngine(nn.Module):
         if sig != self._signature:
             for h in self._hooks:
                 h.remove()
+            if self._buckets:
+                gradsink.unregister([p for b in self._buckets for p in b.params])
             self._hooks, self._buckets, self._bucket_of = [], [], {}
             cur, cur_bytes = [], 0
             for p in reversed(params):                       # gradients become ready roughly in reverse order
@@ -125,6 +154,7 @@ class DataParallelEngine(nn.Module):
                 for pi, p in enumerate(b.params):
                     self._bucket_of[id(p)] = (bi, pi)
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+                    gradsink.register(p, lambda b=b, pi=pi: b.fresh_view(pi))     # the gradient kernels write into the bucket
             self._signature = sig
         for b in self._buckets:
             b.pending = len(b.params)
@@ -139,14 +169,21 @@ class DataParallelEngine(nn.Module):
         b = self._buckets[bi]
         view = b.views[pi]
         if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)                               # zero_grad(set_to_none=True) re-materialised the grad
+            view.copy_(p.grad)                               # a producer that did not write into the bucket (gradsink): copy
             p.grad = view
+            self.stats["grad_copies"] += 1
         b.pending -= 1
         if b.pending == 0:
-            b.work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.measure_comm and b.flat.is_cuda:
+            b.ev0 = torch.cuda.Event(enable_timing=True)
+            b.ev0.record()
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM,
+                                 group=self.process_group, async_op=True)
 
     def _finish(self):
-        inv = 1.0 / self.world
         for b in self._buckets:
             if b.work is None:                               # bucket with parameters that got no gradient
                 for p, v in zip(b.params, b.views):
@@ -156,11 +193,32 @@ class DataParallelEngine(nn.Module):
                     elif p.grad.data_ptr() != v.data_ptr():
                         v.copy_(p.grad)
                         p.grad = v
-                b.work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
+                        self.stats["grad_copies"] += 1
+                self._launch(b)
+        ev_a = ev_b = None
+        if self.measure_comm and self._buckets[0].flat.is_cuda:
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_a.record()                                    # the compute stream has everything of the backward pass queued
         for b in self._buckets:
-            b.work.wait()
-            b.flat.mul_(inv)                                 # mean over ranks, like DataParallel's mean over the batch
+            b.work.wait()                                    # (the compute stream waits for the collective; the host does not)
+        if ev_b is not None:
+            ev_b.record()
+            self._pending_events = (ev_a, ev_b)
+        self.stats["steps"] += 1
         self._callback_queued = False
+
+    def comm_report(self):
+        """Observability of the N > 1 path (bench.py): ranks, bucket sizes, and — when ``measure_comm`` was on — the time the compute
+        stream spent between the last backward kernel and the last collective (= communication NOT hidden behind the backward)."""
+        rep = {"ranks": self.world, "backend": dist.get_backend(self.process_group) if self.world > 1 else None,
+               "reduce_op": "avg (in the collective)" if self._native_avg else "sum of gradients pre-scaled by 1/ranks at the network output",
+               "buckets_MB": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in (self._buckets or [])],
+               "grad_copies": self.stats["grad_copies"], "bucket_scale_kernels": self.stats["bucket_scale_kernels"], "steps": self.stats["steps"]}
+        ev = getattr(self, "_pending_events", None)
+        if ev is not None:
+            torch.cuda.synchronize()
+            rep["exposed_comm_ms_last_step"] = ev[0].elapsed_time(ev[1])
+        return rep
 
 
 def shard_indices(n, rank, world, epoch_seed=None, with_valid=False):

@@ -6,6 +6,7 @@ reference's ResNet never uses raise instead of silently falling back to a librar
 import torch
 
 from . import _lib as L
+from . import gradsink
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -115,6 +116,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         L.check(L.lib().dir_bn_relu_maxpool_fwd(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), n, h, w, c, stream),
                 "dir_bn_relu_maxpool_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd, idx)
+        ctx.beta_sink = gradsink.lookup(beta)
         return y
 
     @staticmethod
@@ -126,8 +128,8 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dev = x.device
         dx = torch.empty_like(x)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dgamma = gradsink.out_for(gamma, (c,), dev)
+        dbeta = gradsink.out_for(ctx.beta_sink, (c,), dev)
         ws = torch.empty(L.lib().dir_bn_relu_maxpool_bwd_workspace(c), dtype=torch.uint8, device=dev)
         L.check(L.lib().dir_bn_relu_maxpool_bwd(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
                                                 L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),

@@ -10,6 +10,7 @@ features when ``fds`` is given (what the reference returns as ``encoding``, SURV
 import torch
 
 from . import _lib as L
+from . import gradsink
 from . import ops
 
 _DT = {torch.bfloat16: L.DIR_BF16, torch.float32: L.DIR_F32}
@@ -41,6 +42,7 @@ class _TailFn(torch.autograd.Function):
         ctx.save_for_backward(enc, bins, scale, w32)
         ctx.in_shape, ctx.in_dtype = (b, c, h, w), x.dtype
         ctx.w_shape, ctx.b_shape = weight.shape, bias.shape
+        ctx.sinks = (gradsink.lookup(weight), gradsink.lookup(bias))
         return pred, enc
 
     @staticmethod
@@ -55,8 +57,8 @@ class _TailFn(torch.autograd.Function):
             denc = denc.float().contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx = torch.empty((b, c, h, w), dtype=ctx.in_dtype, device=dev, memory_format=torch.channels_last) if need_x else None
-        dw = torch.empty(c, dtype=torch.float32, device=dev) if need_w else None
-        db = torch.empty(1, dtype=torch.float32, device=dev) if need_w else None
+        dw = gradsink.out_for(ctx.sinks[0], (c,), dev) if need_w else None      # (bucket slots of the data-parallel engine, if any)
+        db = gradsink.out_for(ctx.sinks[1], (1,), dev) if need_w else None
         ws = torch.empty(max(int(L.lib().dir_tail_bwd_workspace(b, c)), 256), dtype=torch.uint8, device=dev) if need_w else None
         L.check(L.lib().dir_tail_bwd(L.ptr(dpred), L.ptr(denc), L.ptr(bins), L.ptr(scale), L.ptr(w32), L.ptr(enc), b, h * w, c,
                                      _DT[ctx.in_dtype], L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), 0 if ws is None else ws.numel(),

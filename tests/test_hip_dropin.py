@@ -269,6 +269,25 @@ def _train_worker(rank, world, port, tmp):
     assert len(eng._buckets) >= 3
     torch.cuda.synchronize()
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(tmp, f"model{rank}.pt"))
+    # ---- what the engine itself launches per step: a third step under the profiler (the saved parameters are those of two steps)
+    import json
+    from torch.profiler import ProfilerActivity, profile
+    eng.measure_comm = True
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        sl = slice(rank * 8, rank * 8 + 8)
+        x, y, w = (torch.tensor(d[k][1, sl]).cuda() for k in ("x", "y", "w"))
+        train_step(eng, opt, x, y, w, 0, resolve_loss("l1"))
+        torch.cuda.synchronize()
+    ops = {}
+    for e in prof.events():
+        if e.name in ("aten::copy_", "aten::mul", "aten::mul_", "aten::add_", "aten::zero_"):
+            ops[e.name] = ops.get(e.name, 0) + 1
+    rep = eng.comm_report()
+    rep["aten_ops_in_one_train_step"] = ops
+    rep["grad_is_bucket_view"] = all(p.grad is not None and p.grad.data_ptr() == eng._buckets[eng._bucket_of[id(p)][0]].views[eng._bucket_of[id(p)][1]].data_ptr()
+                                     for p in eng.parameters())
+    with open(os.path.join(tmp, f"comm{rank}.json"), "w") as f:
+        json.dump(rep, f)
     dist.destroy_process_group()
 
 
@@ -291,6 +310,22 @@ def test_two_rank_train_steps_equal_single_process_emulation(tmp_path):
     params = [k for k in m0 if "running_" not in k and "num_batches" not in k and "FDS" not in k]
     for k in params:
         assert torch.equal(m0[k], m1[k]), f"ranks diverged on {k}"
+    # the engine adds NO per-parameter work to a step: every gradient kernel wrote straight into its bucket slot (no copy_ per
+    # parameter: 161 of them before), the mean over ranks costs one [B, 1] multiply (gloo) or nothing (RCCL: AVG in the collective)
+    import json
+    for rank in (0, 1):
+        rep = json.load(open(tmp_path / f"comm{rank}.json"))
+        assert rep["ranks"] == 2 and rep["grad_copies"] == 0 and rep["bucket_scale_kernels"] == 0 and rep["grad_is_bucket_view"], rep
+        assert len(rep["buckets_MB"]) >= 3 and abs(sum(rep["buckets_MB"]) - 23510081 * 4 / 2 ** 20) < 0.1, rep
+        ops = rep["aten_ops_in_one_train_step"]
+        # (copy_: the three host -> device input copies of this worker, the bf16 input cast, and gloo's device <-> host staging of each
+        # bucket — nothing per parameter)
+        assert ops.get("aten::copy_", 0) <= 8 + 2 * len(rep["buckets_MB"]) and ops.get("aten::mul", 0) <= 2 and ops.get("aten::mul_", 0) == 0, rep
+        assert "exposed_comm_ms_last_step" in rep
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "two_rank_comm_report.json"), "w") as f:
+        json.dump(json.load(open(tmp_path / "comm0.json")), f, indent=1)
     # single-process emulation: replicas = two BN-buffer sets over shared parameters
     torch.manual_seed(5)
     replicas = [resnet50(fds=True, **FDS_KW).cuda().to(memory_format=torch.channels_last) for _ in range(2)]
@@ -346,3 +381,13 @@ def test_bench_multi_rank_control_flow_two_processes_one_gpu(tmp_path):
     assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp2" and r["config"]["epoch_tails_in_timed_region"] == 2
     assert abs(r["value"] - 4 * 16 * 2 / (r["ms_per_step"] * 4 / 1e3)) <= 1e-6 * r["value"]     # whole-job aggregate over both ranks
     assert np.isfinite(r["config"]["final_loss"])
+    # N > 1 observability: ranks, buckets (94 MB in all), isolated all-reduce times + bus bandwidth, exposed communication per step,
+    # and no per-parameter gradient copies / bucket-wide scale kernels from the engine
+    c = r["comm"]
+    assert c["rccl_ranks"] == 2 and c["backend"] == "gloo" and len(c["buckets"]) == 3, c
+    assert abs(sum(b["MB"] for b in c["buckets"]) - 23510081 * 4 / 2 ** 20) < 0.1 and all(b["allreduce_ms"] > 0 and b["bus_GBs"] > 0 for b in c["buckets"]), c
+    assert c["grad_copies_per_step"] == 0 and c["bucket_scale_kernels"] == 0 and c["exposed_comm_ms_per_step"] is not None, c
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_two_ranks_one_gpu.json"), "w") as f:
+        json.dump(r, f, indent=1)
