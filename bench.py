@@ -343,7 +343,7 @@ def fds_kernel_rooflines(device):
         m2 = torch.randn(nb, c, device=device, generator=g)
         u = int(torch.unique(labb.clamp(max=99)).numel())
         ms = event_time_ms(lambda i: ops.smooth_fwd_(x, labb, 0, 100, m1, sc, m2), 50 if b == 256 else 10)
-        out.append(row("dir_fds_smooth_fwd (K1+K5 fused)" if b <= 2048 else "dir_fds_smooth_fwd (K1, K5)", "hbm" if b > 2048 else "launch",
+        out.append(row("dir_fds_smooth_fwd (K1+K5 fused)" if b <= 2048 else "dir_fds_smooth_fwd (K1, K5 with the tables staged in LDS)", "hbm" if b > 2048 else "launch",
                        f"B={b} C={c} U={u} T=3 f32", ms, 2 * b * c * 4 + 3 * u * c * 4 + b * 4))
         bins_b, _ = ops.bin_index(labb, 0, 100)
         dy = torch.randn(b, c, device=device, generator=g)
@@ -359,6 +359,12 @@ def fds_kernel_rooflines(device):
     ms = event_time_ms(lambda i: ops.calibrate_fwd_(rows, bins, t1, sc, t2), 10)
     out.append(row("dir_fds_calibrate_fwd (narrow rows, NYUD2 dense map)", "hbm", f"[{b},{c},{h},{w}] f32, 93 buckets", ms,
                    2 * rows.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4))
+    fmap = torch.rand(b, c, h, w, device=device, generator=g)
+    outm = torch.empty_like(fmap)
+    ms = event_time_ms(lambda i: ops.calibrate_nchw(fmap, bins, t1, sc, t2, out=outm), 10)
+    out.append(row("dir_fds_calibrate_fwd_nchw (NYUD2 map in its own NCHW layout, tables in LDS)", "hbm", f"[{b},{c},{h},{w}] f32, 93 buckets", ms,
+                   2 * fmap.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4))
+    del fmap, outm
     ms = event_time_ms(lambda i: ops.scatter_stats(rows, bins, 93), 5)
     out.append(row("dir_fds_scatter_stats (narrow rows, NYUD2 dense map)", "hbm", f"N={rows.shape[0]} C={c} Nb=93 f32", ms,
                    rows.numel() * 4 + rows.shape[0] * 4))

@@ -723,6 +723,203 @@ extern "C" int dir_fds_calibrate_bwd(const void* dy, void* dx, int dtype, const 
     return DIR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Calibration with the bin-statistic tables STAGED IN LDS (large batches: the per-row kernel above re-reads its three
+// table rows through the L2 for every feature row — 4 x the HBM bytes at B = 65 536 — and stops at 5.0 TB/s).
+// A workgroup owns a TILE of TW = 128 columns and keeps that tile of ALL nb rows of the three tables resident
+// (3 x nb x 128 floats = 150 KB at nb = 100: one workgroup per CU, 1024 threads), then streams its range of feature rows in
+// their natural order: 32 lanes cover the 512-byte slice of a row, every lane keeps four rows in flight (non-temporal 16-byte
+// loads / stores), and the table values come from LDS with the row's bin as the index — conflict free (16 lanes of a
+// ds_read_b128 group read 256 contiguous bytes). No sort, no atomics, the arithmetic of calib1 unchanged: bit-identical results.
+// Replaces imdb-wiki-dir/fds.py:120-143 / utils.py:97-107 for B >= FDS_LDS_MIN_ROWS and the NHWC form of the NYUD2 map.
+// ---------------------------------------------------------------------------------------------
+#define FDS_LDS_TPB 1024
+#define FDS_LDS_MIN_ROWS 4096
+template <int TW, int TPB = FDS_LDS_TPB>
+__global__ void __launch_bounds__(TPB)
+fds_calibrate_lds_kernel(float* __restrict__ x, const int32_t* __restrict__ bins, long long B, int C, int nb,
+                         const float* __restrict__ m1, const float* __restrict__ scale, const float* __restrict__ m2,
+                         long long rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float fds_tab[];      // [3][nb][TW]
+    constexpr int TPR = TW / 4;                                          // lanes per row slice
+    const int t = threadIdx.x;
+    const int col0 = blockIdx.x * TW;
+    {
+        const float* src[3] = {m1, scale, m2};
+        const int per = nb * TPR;
+        for (int i = t; i < 3 * per; i += TPB) {
+            const int which = i / per, rem = i - which * per, b = rem / TPR, c4 = rem - b * TPR;
+            float4 v = make_float4(0.f, -1.f, 0.f, 0.f);
+            if (col0 + c4 * 4 < C) v = *reinterpret_cast<const float4*>(src[which] + (size_t)b * C + col0 + c4 * 4);
+            *reinterpret_cast<float4*>(fds_tab + ((size_t)which * nb + b) * TW + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    const int tc = t % TPR, tl = t / TPR;
+    constexpr int RPP = TPB / TPR;                               // rows per pass of the workgroup
+    const int col = col0 + tc * 4;
+    if (col >= C) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < B) ? r0 + rows_per_wg : B;
+    const float4* t1 = reinterpret_cast<const float4*>(fds_tab) + tc;
+    const float4* ts = reinterpret_cast<const float4*>(fds_tab + (size_t)nb * TW) + tc;
+    const float4* t2 = reinterpret_cast<const float4*>(fds_tab + (size_t)2 * nb * TW) + tc;
+    for (long long row = r0 + tl; row < r1; row += 4 * RPP) {
+        int bn[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = row + (long long)u * RPP;
+            bn[u] = (r < r1) ? bins[r] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = row + (long long)u * RPP;
+            v[u] = (bn[u] >= 0) ? fds_ldnt(x + (size_t)r * C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (bn[u] < 0) continue;
+            const long long r = row + (long long)u * RPP;
+            const float4 a = t1[bn[u] * TPR], sc = ts[bn[u] * TPR], c = t2[bn[u] * TPR];
+            float4 o;
+            o.x = calib1(v[u].x, a.x, sc.x, c.x); o.y = calib1(v[u].y, a.y, sc.y, c.y);
+            o.z = calib1(v[u].z, a.z, sc.z, c.z); o.w = calib1(v[u].w, a.w, sc.w, c.w);
+            fds_stnt(x + (size_t)r * C + col, o);
+        }
+    }
+}
+
+static int fds_calibrate_lds_launch(float* x, const int32_t* bins, long long B, int C, int nb, const float* m1, const float* scale,
+                                    const float* m2, hipStream_t s) {
+    // widest column tile whose three table slices fit the 160 KB of a CU (64 KB when that allows two workgroups per CU)
+    int tw = 128;
+    while (tw > 16 && (size_t)3 * nb * tw * 4 > 160 * 1024) tw >>= 1;
+    if ((size_t)3 * nb * tw * 4 > 160 * 1024) return -1;
+    const int nct = dir_cdiv(C, tw);
+    int ny = dir_cdiv(512, nct);
+    const long long min_rows = 4 * (FDS_LDS_TPB / (tw / 4));
+    if ((long long)ny * min_rows > B) ny = (int)((B + min_rows - 1) / min_rows);
+    if (ny < 1) ny = 1;
+    const long long rows_per_wg = (B + ny - 1) / ny;
+    const size_t lds = (size_t)3 * nb * tw * 4;
+#define FDS_LDS_GO(TW_)                                                                                                        \
+    {                                                                                                                          \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_lds_kernel<TW_>),            \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);          \
+        (void)once;                                                                                                            \
+        hipLaunchKernelGGL(fds_calibrate_lds_kernel<TW_>, dim3(nct, ny), dim3(FDS_LDS_TPB), lds, s, x, bins, B, C, nb, m1, scale, m2, rows_per_wg); \
+    }
+    if (tw == 128) FDS_LDS_GO(128) else if (tw == 64) FDS_LDS_GO(64) else if (tw == 32) FDS_LDS_GO(32) else FDS_LDS_GO(16)
+#undef FDS_LDS_GO
+    return 0;
+}
+
+// Forward calibration of B rows with the tables staged in LDS; nb = rows of the tables (bins are in [0, nb) or < 0 = row untouched).
+// Falls back to dir_fds_calibrate_fwd when the layout does not allow 16-byte accesses or nb is too large for a CU's LDS.
+extern "C" int dir_fds_calibrate_fwd_lds(void* x_inout, int dtype, const int32_t* bins, long long B, int C, int nb,
+                                         const float* m1, const float* scale, const float* m2, dir_stream_t stream) {
+    DIR_RETURN_IF(B < 0 || C <= 0 || nb <= 0, DIR_EINVAL);
+    if (B == 0) return DIR_OK;
+    DIR_RETURN_IF(!x_inout || !bins || !m1 || !scale || !m2, DIR_EINVAL);
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    float* x = static_cast<float*>(x_inout);
+    if (vec4_ok(C, x, m1, scale, m2) && fds_calibrate_lds_launch(x, bins, B, C, nb, m1, scale, m2, dir_s(stream)) == 0) {
+        DIR_LAUNCH_CHECK();
+        return DIR_OK;
+    }
+    DIR_RETURN_IF(B > 0x7fffffffll, DIR_EUNSUPPORTED);
+    return dir_fds_calibrate_fwd(x_inout, dtype, bins, (int)B, C, m1, scale, m2, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NYUD2-DIR dense variant on the network's own NCHW feature map (nyud2-dir/models/fds.py:128-149 permutes it to [B*H*W, C],
+// calibrates per pixel and permutes back: two 284 MB copies around the pass). Here the map is read and written in place of
+// those copies: a lane owns FOUR consecutive pixels of a channel plane (16-byte coalesced accesses along W), walks the C
+// channels, and looks the (bin, channel) table values up in LDS, where all three tables live TRANSPOSED as [C][nbp] so that the
+// lanes of a wavefront — same channel, neighbouring pixels, nearby bins — hit different banks (or broadcast).
+// BWD: dx = dy * scale (scale < 0: untouched column) with only the multiplier table staged.
+// ---------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(FDS_LDS_TPB)
+fds_calibrate_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ bins,
+                          long long npix, int C, int HW, int nb, int nbp,
+                          const float* __restrict__ m1, const float* __restrict__ scale, const float* __restrict__ m2) {
+    extern __shared__ __attribute__((aligned(16))) float fds_tab[];      // [T][C][nbp], T = 3 (forward: m1, scale, m2) or 1 (scale)
+    const int t = threadIdx.x;
+    {
+        const float* src[3] = {BWD ? scale : m1, scale, m2};
+        const int T = BWD ? 1 : 3;
+        for (int i = t; i < T * nb * C; i += FDS_LDS_TPB) {              // coalesced over the [nb][C] source
+            const int which = i / (nb * C), rem = i - which * nb * C, b = rem / C, c = rem - b * C;
+            fds_tab[((size_t)which * C + c) * nbp + b] = src[which][rem];
+        }
+    }
+    __syncthreads();
+    const float* t1 = fds_tab;
+    const float* ts = BWD ? fds_tab : fds_tab + (size_t)C * nbp;
+    const float* t2 = fds_tab + (size_t)2 * C * nbp;
+    const long long nquad = npix >> 2;
+    for (long long q = (long long)blockIdx.x * FDS_LDS_TPB + t; q < nquad; q += (long long)gridDim.x * FDS_LDS_TPB) {
+        const long long p = q << 2;
+        const long long n = p / HW;
+        const int hw = (int)(p - n * HW);
+        const int4 b4 = *reinterpret_cast<const int4*>(bins + p);
+        const int bn[4] = {b4.x, b4.y, b4.z, b4.w};
+        const size_t base = (size_t)n * C * HW + hw;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float4 v = fds_ldnt(x + base + (size_t)c * HW);
+            float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (bn[k] < 0) { out[k] = in[k]; continue; }
+                const float sc = ts[c * nbp + bn[k]];
+                if (BWD) out[k] = sc < 0.0f ? in[k] : in[k] * sc;
+                else out[k] = calib1(in[k], t1[c * nbp + bn[k]], sc, t2[c * nbp + bn[k]]);
+            }
+            fds_stnt(y + base + (size_t)c * HW, make_float4(out[0], out[1], out[2], out[3]));
+        }
+    }
+}
+
+// x, y: [N, C, HW] float32 (NCHW maps, HW = H * W a multiple of 4, 16-byte aligned); bins: [N * HW] int32 (< 0: pixel copied
+// unchanged). y may alias x. Returns DIR_EUNSUPPORTED when the tables do not fit a CU's LDS or the layout does not allow
+// 16-byte accesses (the caller then takes the row form).
+static int fds_nchw_launch(bool bwd, const float* x, float* y, const int32_t* bins, long long N, int C, int HW, int nb,
+                           const float* m1, const float* scale, const float* m2, dir_stream_t stream) {
+    DIR_RETURN_IF(N < 0 || C <= 0 || HW <= 0 || nb <= 0, DIR_EINVAL);
+    if (N == 0) return DIR_OK;
+    DIR_RETURN_IF(!x || !y || !bins || !scale || (!bwd && (!m1 || !m2)), DIR_EINVAL);
+    DIR_RETURN_IF((HW & 3) || !dir_aligned16(x) || !dir_aligned16(y) || !dir_aligned16(bins), DIR_EUNSUPPORTED);
+    const int nbp = (nb + 3) & ~3;
+    const size_t lds = (size_t)(bwd ? 1 : 3) * C * nbp * 4;
+    DIR_RETURN_IF(lds > 160 * 1024, DIR_EUNSUPPORTED);
+    const long long npix = N * (long long)HW;
+    long long want = (npix / 4 + FDS_LDS_TPB - 1) / FDS_LDS_TPB;
+    int grid = (int)(want < 256 ? (want < 1 ? 1 : want) : 256);
+    if (lds <= 64 * 1024 && want > 256) grid = (int)(want < 512 ? want : 512);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    if (bwd) hipLaunchKernelGGL(fds_calibrate_nchw_kernel<true>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
+    else hipLaunchKernelGGL(fds_calibrate_nchw_kernel<false>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_fds_calibrate_fwd_nchw(const void* x, void* y, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
+                                          const float* m1, const float* scale, const float* m2, dir_stream_t stream) {
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    return fds_nchw_launch(false, static_cast<const float*>(x), static_cast<float*>(y), bins, N, C, HW, nb, m1, scale, m2, stream);
+}
+
+extern "C" int dir_fds_calibrate_bwd_nchw(const void* dy, void* dx, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
+                                          const float* scale, dir_stream_t stream) {
+    DIR_RETURN_IF(dtype != DIR_F32, DIR_EUNSUPPORTED);
+    return fds_nchw_launch(true, static_cast<const float*>(dy), static_cast<float*>(dx), bins, N, C, HW, nb, nullptr, scale, nullptr, stream);
+}
+
 #define SMOOTH_FUSED_MAX_B 2048
 
 extern "C" int dir_fds_smooth_fwd(void* x_inout, int dtype, const float* labels, int B, int C,
@@ -742,6 +939,8 @@ extern "C" int dir_fds_smooth_fwd(void* x_inout, int dtype, const float* labels,
         uint32_t* flags = reinterpret_cast<uint32_t*>(bins_out + B);
         int rc = dir_fds_bin_index(labels, B, bucket_start, bucket_num, bins_out, flags, stream);
         if (rc) return rc;
+        if (B >= FDS_LDS_MIN_ROWS)      // tables staged in LDS, rows streamed in their natural order
+            return dir_fds_calibrate_fwd_lds(x_inout, dtype, bins_out, B, C, bucket_num - bucket_start, m1, scale, m2, stream);
         return dir_fds_calibrate_fwd(x_inout, dtype, bins_out, B, C, m1, scale, m2, stream);
     }
     if (vec4_ok(C, x, m1, scale, m2)) {

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libdir_hip.so")
 
 c_int, c_float, c_double, c_void_p, c_size_t, c_int64 = (
     ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64)
+c_longlong = ctypes.c_longlong
+DIR_EUNSUPPORTED = -2
 
 # name -> (restype, argtypes); must list every symbol of include/dir_hip.h
 SIGNATURES = {
@@ -31,6 +33,9 @@ SIGNATURES = {
     "dir_fds_prepare_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "dir_fds_calibrate_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dir_fds_calibrate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dir_fds_calibrate_fwd_lds": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_calibrate_fwd_nchw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_calibrate_bwd_nchw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dir_fds_smooth_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "dir_weighted_loss_workspace": (c_size_t, [c_int]),

@@ -31,6 +31,36 @@ def _rows(features):
     return f.contiguous().view(-1, c), (b, h, w, c)
 
 
+def _nchw_ok(t):
+    return t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous() and (t.shape[2] * t.shape[3]) % 4 == 0
+
+
+class _DenseSmoothNCHWFn(torch.autograd.Function):
+    """The calibration on the network's own NCHW map, tables resident in LDS (``dir_fds_calibrate_*_nchw``): no permuted copy of the
+    284 MB map before and after (nyud2-dir/models/fds.py:136,149). Returns a NEW tensor (fds.py:136 works on a copy)."""
+
+    @staticmethod
+    def forward(ctx, features, bins, m1, scale, m2):
+        y = ops.calibrate_nchw(features, bins, m1, scale, m2)
+        if y is None:
+            raise L.DirHipError("dir_fds_calibrate_fwd_nchw does not take this geometry")
+        ctx.save_for_backward(bins, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        bins, scale = ctx.saved_tensors
+        g = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.float().contiguous()
+        dx = ops.calibrate_bwd_nchw(g, bins, scale)
+        if dx is None:
+            raise L.DirHipError("dir_fds_calibrate_bwd_nchw does not take this geometry")
+        return dx, None, None, None, None
+
+
+def _nchw_fits(c, nb):
+    return 3 * c * ((nb + 3) // 4 * 4) * 4 <= 160 * 1024
+
+
 class _DenseSmoothFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, bins, m1, scale, m2):
@@ -99,8 +129,9 @@ class FDS(_AgeFDS):
         if not features.is_cuda:
             raise L.DirHipError(f"features on {features.device}: FDS runs only as HIP kernels on an AMD GPU (no CPU fallback)")
         assert features.dim() == 4 and features.size(1) == self.feature_dim
-        return _DenseSmoothFn.apply(features, self._bins(labels.squeeze(1)), self.running_mean_last_epoch.contiguous(),
-                                    self._scale_table(), self.smoothed_mean_last_epoch.contiguous())
+        fn = _DenseSmoothNCHWFn if (_nchw_ok(features) and _nchw_fits(features.shape[1], self.bucket_num - self.bucket_start)) else _DenseSmoothFn
+        return fn.apply(features, self._bins(labels.squeeze(1)), self.running_mean_last_epoch.contiguous(),
+                        self._scale_table(), self.smoothed_mean_last_epoch.contiguous())
 
 
 def calibrate_mean_var(matrix, m1, v1, m2, v2, clip_min=0.2, clip_max=5., per_column_guard=False):

@@ -131,9 +131,46 @@ def prepare_scale(v1, v2, clip_min=0.1, clip_max=10.0, out=None, guard_mode=0):
 
 def calibrate_fwd_(x, bins, m1, scale, m2):
     b, c = x.shape
+    if b >= LDS_STAGED_MIN_ROWS:
+        return calibrate_fwd_lds_(x, bins, m1, scale, m2)
     L.check(L.lib().dir_fds_calibrate_fwd(L.ptr(x), L.DIR_F32, L.ptr(bins), b, c, L.ptr(m1), L.ptr(scale),
                                           L.ptr(m2), L.stream_ptr(x.device)), "dir_fds_calibrate_fwd")
     return x
+
+
+LDS_STAGED_MIN_ROWS = 4096     # from here on the tables are staged in LDS (dir_fds_calibrate_fwd_lds); below, the launch dominates
+
+
+def calibrate_fwd_lds_(x, bins, m1, scale, m2):
+    """In place on x [B, C] with the three [nb, C] tables staged in LDS (any B; meant for B >= LDS_STAGED_MIN_ROWS)."""
+    b, c = x.shape
+    L.check(L.lib().dir_fds_calibrate_fwd_lds(L.ptr(x), L.DIR_F32, L.ptr(bins), b, c, m1.shape[0], L.ptr(m1), L.ptr(scale),
+                                              L.ptr(m2), L.stream_ptr(x.device)), "dir_fds_calibrate_fwd_lds")
+    return x
+
+
+def calibrate_nchw(x, bins, m1, scale, m2, out=None):
+    """NYUD2 dense variant on an NCHW float32 map x [N, C, H, W] (contiguous), bins [N*H*W] int32: returns the calibrated map (new
+    tensor unless ``out``), or None when the kernel does not take the geometry (caller falls back to the row form)."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x) if out is None else out
+    rc = L.lib().dir_fds_calibrate_fwd_nchw(L.ptr(x), L.ptr(y), L.DIR_F32, L.ptr(bins), n, c, h * w, m1.shape[0], L.ptr(m1), L.ptr(scale),
+                                            L.ptr(m2), L.stream_ptr(x.device))
+    if rc == L.DIR_EUNSUPPORTED:
+        return None
+    L.check(rc, "dir_fds_calibrate_fwd_nchw")
+    return y
+
+
+def calibrate_bwd_nchw(dy, bins, scale):
+    n, c, h, w = dy.shape
+    dx = torch.empty_like(dy)
+    rc = L.lib().dir_fds_calibrate_bwd_nchw(L.ptr(dy), L.ptr(dx), L.DIR_F32, L.ptr(bins), n, c, h * w, scale.shape[0], L.ptr(scale),
+                                            L.stream_ptr(dy.device))
+    if rc == L.DIR_EUNSUPPORTED:
+        return None
+    L.check(rc, "dir_fds_calibrate_bwd_nchw")
+    return dx
 
 
 def calibrate_bwd(dy, bins, scale):

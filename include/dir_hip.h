@@ -135,6 +135,21 @@ int dir_fds_calibrate_fwd(void* x_inout, int dtype, const int32_t* bins, int B, 
 /* K6  its autograd:  dx[r, c] = (bins[r] < 0 || scale < 0) ? dy : dy * scale.  dx may alias dy. */
 int dir_fds_calibrate_bwd(const void* dy, void* dx, int dtype, const int32_t* bins, int B, int C,
                           const float* scale, dir_stream_t stream);
+/* K5 with the bin-statistic tables STAGED IN LDS (large batches, B >= 4096; imdb-wiki-dir/fds.py:120-143): a workgroup keeps a
+ * 128-column tile of all nb rows of (m1, scale, m2) resident (150 KB at nb = 100) and streams feature rows in their natural order,
+ * four rows in flight per lane — no table re-reads through the L2, no sort.  Same arithmetic, bit-identical to dir_fds_calibrate_fwd.
+ * nb = rows of the tables; bins in [0, nb) or < 0 (row untouched).  Falls back to dir_fds_calibrate_fwd when the layout does not
+ * allow 16-byte accesses or nb x 16 columns x 12 B exceed a CU's LDS. */
+int dir_fds_calibrate_fwd_lds(void* x_inout, int dtype, const int32_t* bins, long long B, int C, int nb,
+                              const float* m1, const float* scale, const float* m2, dir_stream_t stream);
+/* K5 / K6 of the NYUD2-DIR dense variant on the network's own NCHW map (nyud2-dir/models/fds.py:128-149 permutes the map to
+ * [B*H*W, C] and back around the calibration: two copies of 284 MB).  x, y: [N, C, HW] float32, HW % 4 == 0, 16-byte aligned;
+ * bins [N * HW] int32 per pixel (< 0: copied unchanged); all three [nb, C] tables live transposed in LDS ([C][nb]); y may alias x.
+ * DIR_EUNSUPPORTED when the tables do not fit (3 x C x nb x 4 B > 160 KB) or the layout does not allow 16-byte accesses. */
+int dir_fds_calibrate_fwd_nchw(const void* x, void* y, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
+                               const float* m1, const float* scale, const float* m2, dir_stream_t stream);
+int dir_fds_calibrate_bwd_nchw(const void* dy, void* dx, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
+                               const float* scale, dir_stream_t stream);
 /* K1+K5 in one launch for a training batch (FDS.smooth, fds.py:115-144): labels [B] f32;
  * bins_out [B + 1] int32: the first B entries receive the bins for the backward, the last one is
  * scratch.  Any B (falls back to K1 then K5 above a batch-size threshold). */

@@ -514,3 +514,79 @@ def test_nyud2_full_size_whiten_recolor_and_speed():
     dy = torch.randn(rows.shape, device="cuda", generator=g)
     dx = ops.calibrate_bwd(dy, bins, scale)
     assert torch.equal(dx, dy * scale[bins.long()])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 3: calibration with the bin-statistic tables staged in LDS (large batches) and on NCHW maps (NYUD2)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,c,nb", [(65536, 2048, 100), (5003, 2048, 97), (4096, 12000, 50), (100003, 128, 93), (7001, 520, 100), (6000, 2048, 300)])
+def test_calibrate_lds_staged_bit_identical_to_row_kernel(b, c, nb):
+    from dirhip import _lib as L
+    """dir_fds_calibrate_fwd_lds (tables resident in LDS, rows streamed in natural order, 4 rows in flight per lane) against the
+    per-row kernel dir_fds_calibrate_fwd: same arithmetic -> identical bits, rows with bin < 0 untouched, ragged row counts,
+    partial column tiles (C = 520, 12000), narrow rows (C = 128) and a table too tall for a 128-column tile (nb = 300 -> 32)."""
+    from dirhip import ops
+    g = torch.Generator(device="cuda").manual_seed(b + c)
+    x = torch.randn(b, c, device="cuda", generator=g)
+    bins = torch.randint(-1, nb, (b,), device="cuda", generator=g, dtype=torch.int32)
+    m1 = torch.randn(nb, c, device="cuda", generator=g)
+    sc = torch.rand(nb, c, device="cuda", generator=g) + 0.5
+    sc[torch.rand(nb, c, device="cuda", generator=g) < 0.05] = -1.0          # "leave untouched" columns (v1 == 0, utils.py:100-104)
+    m2 = torch.randn(nb, c, device="cuda", generator=g)
+    want = x.clone()
+    L.check(L.lib().dir_fds_calibrate_fwd(L.ptr(want), L.DIR_F32, L.ptr(bins), b, c, L.ptr(m1), L.ptr(sc), L.ptr(m2), L.stream_ptr(x.device)), "row kernel")
+    got = ops.calibrate_fwd_lds_(x.clone(), bins, m1, sc, m2)
+    assert torch.equal(got, want)
+    assert torch.equal(got[bins < 0], x[bins < 0])
+
+
+def test_smooth_large_batch_takes_lds_path_and_matches_oracle():
+    """FDS.smooth at B = 8192 (dir_fds_smooth_fwd -> K1 + the LDS-staged calibration) bit-equal to the numpy oracle's
+    calibrate_mean_var given the same tables and bins."""
+    from dirhip import ops
+    rng = np.random.default_rng(5)
+    b, c, nb = 8192, 2048, 100
+    x = rng.normal(0, 1, (b, c)).astype(np.float32)
+    labels = np.clip(np.round(np.abs(rng.normal(0, 18, b)) + 20), 0, 120).astype(np.float32)
+    m1 = rng.normal(0, 1, (nb, c)).astype(np.float32)
+    v1 = rng.uniform(0.5, 2, (nb, c)).astype(np.float32)
+    v2 = rng.uniform(0.5, 2, (nb, c)).astype(np.float32)
+    m2 = rng.normal(0, 1, (nb, c)).astype(np.float32)
+    scale = ops.prepare_scale(dev(v1), dev(v2), 0.1, 10.0)
+    xd = dev(x.copy())
+    bins = ops.smooth_fwd_(xd, dev(labels), 0, 100, dev(m1), scale, dev(m2))[:b].cpu().numpy()
+    want = x.copy()
+    for bb in np.unique(bins):
+        if bb < 0:
+            continue
+        rows = bins == bb
+        want[rows] = fds_oracle.calibrate_mean_var(x[rows], m1[bb], v1[bb], m2[bb], v2[bb])
+    assert np.array_equal(xd.cpu().numpy(), want)
+
+
+def test_nyud2_nchw_calibration_bit_identical_to_row_form():
+    from dirhip import _lib as L
+    """dir_fds_calibrate_{fwd,bwd}_nchw on the [32, 128, 114, 152] map (tables transposed in LDS, 4 pixels per lane) against the
+    permute -> row kernel -> permute chain it replaces (nyud2-dir/models/fds.py:136,149): identical bits, input untouched."""
+    from dirhip import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    b, c, h, w, nb = 32, 128, 114, 152, 93
+    depth = torch.rand(b, 1, h, w, device="cuda", generator=g) * 9.3 + 0.7
+    x = torch.rand(b, c, h, w, device="cuda", generator=g)
+    bins = ops.bin_scaled(depth.reshape(-1), 10.0, 7, 100)
+    bins[::1013] = -1
+    m1, m2 = (torch.randn(nb, c, device="cuda", generator=g) for _ in range(2))
+    sc = torch.rand(nb, c, device="cuda", generator=g) + 0.5
+    sc[torch.rand(nb, c, device="cuda", generator=g) < 0.05] = -1.0
+    keep = x.clone()
+    y = ops.calibrate_nchw(x, bins, m1, sc, m2)
+    assert y is not None and torch.equal(x, keep)
+    rows = x.permute(0, 2, 3, 1).contiguous().view(-1, c)
+    L.check(L.lib().dir_fds_calibrate_fwd(L.ptr(rows), L.DIR_F32, L.ptr(bins), rows.shape[0], c, L.ptr(m1), L.ptr(sc), L.ptr(m2), L.stream_ptr(x.device)), "row kernel")
+    assert torch.equal(y, rows.view(b, h, w, c).permute(0, 3, 1, 2))
+    dy = torch.randn(b, c, h, w, device="cuda", generator=g)
+    dx = ops.calibrate_bwd_nchw(dy, bins, sc)
+    want = ops.calibrate_bwd(dy.permute(0, 2, 3, 1).contiguous().view(-1, c), bins, sc).view(b, h, w, c).permute(0, 3, 1, 2)
+    assert torch.equal(dx, want)
+    # geometry the kernel does not take -> None (the module then falls back to the row form)
+    assert ops.calibrate_nchw(torch.rand(2, 128, 5, 5, device="cuda"), torch.zeros(50, dtype=torch.int32, device="cuda"), m1, sc, m2) is None
