@@ -22,13 +22,18 @@ print = logging.info
 
 
 def draw_augment_params(n, pad=16, generator=None):
-    """The random draws of RandomCrop(S, padding=pad) + RandomHorizontalFlip for ``n`` images, per image in torchvision's order
-    (top, then left — both uniform on [0, 2 pad] —, then the flip coin): int32 ``[n, 3]`` = (top, left, flip) on the host."""
+    """The random draws of RandomCrop(S, padding=pad) + RandomHorizontalFlip for ``n`` images: top and left uniform on [0, 2 pad],
+    an independent fair flip coin each — int32 ``[n, 3]`` = (top, left, flip) on the host. A single image (the host transform) draws
+    in torchvision's order; a batch (DeviceAugment) draws with two vectorised calls (B = 256 used to cost 768 tiny RNG calls on the
+    training thread) — same distributions, another stream (torchvision's could not be reproduced across loader workers anyway)."""
     out = torch.empty((n, 3), dtype=torch.int32)
-    for i in range(n):
-        out[i, 0] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))
-        out[i, 1] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))
-        out[i, 2] = int(float(torch.rand(1, generator=generator)) < 0.5)
+    if n == 1:                                                    # the per-image host transform: torchvision's own order of draws
+        out[0, 0] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))      # RandomCrop.get_params: i (top) ...
+        out[0, 1] = int(torch.randint(0, 2 * pad + 1, (1,), generator=generator))      # ... then j (left)
+        out[0, 2] = int(float(torch.rand(1, generator=generator)) < 0.5)               # RandomHorizontalFlip's coin
+    elif n:
+        out[:, :2] = torch.randint(0, 2 * pad + 1, (n, 2), generator=generator, dtype=torch.int32)
+        out[:, 2] = (torch.rand(n, generator=generator) < 0.5).to(torch.int32)
     return out
 
 

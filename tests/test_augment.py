@@ -55,15 +55,18 @@ def test_draw_order_and_ranges():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "imbalanced-regression_amd"))
     from dirhip.datasets import draw_augment_params
     torch.manual_seed(7)
-    p = draw_augment_params(500)
+    one = [draw_augment_params(1)[0].tolist() for _ in range(500)]           # the host transform: one image at a time
     torch.manual_seed(7)
     want = []
     for _ in range(500):                                                     # RandomCrop.get_params: i (top) then j (left); then the flip coin
         i = int(torch.randint(0, 33, (1,)))
         j = int(torch.randint(0, 33, (1,)))
         want.append((i, j, int(float(torch.rand(1)) < 0.5)))
-    assert p.tolist() == [list(w) for w in want]
+    assert one == [list(w) for w in want]
+    p = draw_augment_params(20000)                                           # a batch: vectorised draws, same distributions
     assert p[:, :2].min() == 0 and p[:, :2].max() == 32 and set(p[:, 2].tolist()) == {0, 1}
+    assert abs(p[:, 0].float().mean() - 16) < 0.3 and abs(p[:, 1].float().mean() - 16) < 0.3 and abs(p[:, 2].float().mean() - 0.5) < 0.02
+    assert abs(float(torch.corrcoef(p[:, :2].float().T)[0, 1])) < 0.03
     g = torch.Generator().manual_seed(3)
     a = draw_augment_params(10, generator=g)
     g = torch.Generator().manual_seed(3)
