@@ -263,17 +263,58 @@ bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __r
 // RES: 0 = no residual, 1 = residual tensor added as is, 2 = residual is itself the INPUT of a BatchNorm whose
 // normalisation (rcoef) is applied on the fly (projection shortcut: relu(bn3(x) + bn_d(r)), resnet.py:63-68, without
 // materialising bn_d(r))
+// The FINALIZE step inside the apply pass (round 3): the per-channel statistics -> coefficients arithmetic of
+// bn_finalize_train_kernel used to be a launch of its own between the fold of the partial list and the apply pass — C/8
+// workgroups chasing a chain of L2 round trips, ~5.5 us of an otherwise idle GPU per BatchNorm and pass (106 such launches
+// per training step). Now every workgroup of the apply pass sums the <= BN_FOLD_ROWS folded rows (float64) of ITS channel tile
+// itself — the same arithmetic, in the same order — and the workgroups of row block 0 also write save_mean / save_rstd and the
+// running statistics. fin.folded == nullptr: coefficients come from `coef` as before (eval mode, the two-BatchNorm join).
+constexpr int BN_FOLD_ROWS = 8;
+struct BnFinF {
+    const double* folded; int rows; double n, momentum, eps;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; float* save_mean; float* save_rstd;
+};
+
 template <typename T, int RES, bool RELU>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t M, int C, BnGeom g,
-                const float* __restrict__ coef, const float* __restrict__ rcoef, uint8_t* __restrict__ bits) {
+                const float* __restrict__ coef, const float* __restrict__ rcoef, uint8_t* __restrict__ bits, BnFinF fin) {
     constexpr int VEC = Vec<T>::N;
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
     const int c = blockIdx.y * g.ct + tg * VEC;
     float a[VEC], b[VEC], a2[VEC], b2[VEC];
+    if (fin.folded) {
+        __shared__ float s_ab[2][DIR_TPB];
+        if (t < g.ct) {
+            const int cc = blockIdx.y * g.ct + t;
+            double s = 0.0, q = 0.0;
+            for (int r = 0; r < fin.rows; ++r) { s += fin.folded[((size_t)r * 2 + 0) * C + cc]; q += fin.folded[((size_t)r * 2 + 1) * C + cc]; }
+            const double mean = s / fin.n;
+            double var = q / fin.n - mean * mean;             // biased (normalisation)
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + fin.eps);
+            const double meanf = (double)(float)mean, rstdf = (double)(float)rstd;   // what the backward will see
+            s_ab[0][t] = (float)((double)fin.gamma[cc] * rstdf);
+            s_ab[1][t] = (float)((double)fin.beta[cc] - meanf * (double)fin.gamma[cc] * rstdf);
+            if (blockIdx.x == 0) {
+                fin.save_mean[cc] = (float)mean;
+                fin.save_rstd[cc] = (float)rstd;
+                if (fin.running_mean) {                        // torch: running = (1-m)*running + m*batch, unbiased var
+                    const double unbiased = fin.n > 1.0 ? var * fin.n / (fin.n - 1.0) : var;
+                    fin.running_mean[cc] = (float)((1.0 - fin.momentum) * (double)fin.running_mean[cc] + fin.momentum * mean);
+                    fin.running_var[cc] = (float)((1.0 - fin.momentum) * (double)fin.running_var[cc] + fin.momentum * unbiased);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { a[j] = s_ab[0][tg * VEC + j]; b[j] = s_ab[1][tg * VEC + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; b[j] = coef[C + c + j]; }
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        a[j] = coef[c + j]; b[j] = coef[C + c + j];
         a2[j] = RES == 2 ? rcoef[c + j] : 1.0f; b2[j] = RES == 2 ? rcoef[C + c + j] : 0.0f;
     }
     const int64_t stride = (int64_t)gridDim.x * g.rpi;
@@ -405,11 +446,18 @@ bn_bwd_finalize_kernel(const PT* __restrict__ partial, int rblocks, int64_t M, i
     coef[2 * C + c] = (float)(-a * sg / n - p * mean);
 }
 
+// (finalize inside the apply pass, as in the forward: bn_bwd_finalize_kernel's arithmetic per channel tile; row block 0 writes
+// dgamma / dbeta)
+struct BnFinB {
+    const double* folded; int rows; double n;
+    const float* gamma; const float* save_mean; const float* save_rstd; float* dgamma; float* dbeta;
+};
+
 template <typename T, int MASK, bool DRES>
 __global__ void __launch_bounds__(DIR_TPB)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ out,
                     T* __restrict__ dx, T* __restrict__ dres, int64_t M, int C, BnGeom g, const float* __restrict__ coef,
-                    BnMaskCoef mc) {
+                    BnMaskCoef mc, BnFinB fin) {
     constexpr int VEC = Vec<T>::N;
     constexpr bool RELU = (MASK == 1);
     const int t = threadIdx.x, tg = t % g.tpr, tr = t / g.tpr;
@@ -417,8 +465,28 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
     float af[VEC], bf[VEC];
     if (MASK == 2) bn_mask_coef<VEC>(mc, c, af, bf);
     float a[VEC], p[VEC], q[VEC];
+    if (fin.folded) {
+        __shared__ float s_apq[3][DIR_TPB];
+        if (t < g.ct) {
+            const int cc = blockIdx.y * g.ct + t;
+            double sg = 0.0, sgx = 0.0;
+            for (int r = 0; r < fin.rows; ++r) { sg += fin.folded[((size_t)r * 2 + 0) * C + cc]; sgx += fin.folded[((size_t)r * 2 + 1) * C + cc]; }
+            const double mean = (double)fin.save_mean[cc], rstd = (double)fin.save_rstd[cc];
+            const double dg = rstd * (sgx - mean * sg);
+            const double ca = (double)fin.gamma[cc] * rstd;
+            const double cp = -ca * rstd * dg / fin.n;
+            s_apq[0][t] = (float)ca;
+            s_apq[1][t] = (float)cp;
+            s_apq[2][t] = (float)(-ca * sg / fin.n - cp * mean);
+            if (blockIdx.x == 0) { fin.dbeta[cc] = (float)sg; fin.dgamma[cc] = (float)dg; }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; p[j] = coef[C + c + j]; q[j] = coef[2 * C + c + j]; }
+        for (int j = 0; j < VEC; ++j) { a[j] = s_apq[0][tg * VEC + j]; p[j] = s_apq[1][tg * VEC + j]; q[j] = s_apq[2][tg * VEC + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; p[j] = coef[C + c + j]; q[j] = coef[2 * C + c + j]; }
+    }
     const int64_t stride = (int64_t)gridDim.x * g.rpi;
     int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
     for (; row + stride < M; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
@@ -558,15 +626,32 @@ bn_bwd_join_apply_kernel(const T* __restrict__ gout, const T* __restrict__ x, co
     }
 }
 
-struct BnWs { float* partial; float* coef; size_t bytes; };
+// A/B switch for tools and tests (process-wide, default 0: measured neutral, profiles/r03_ab_in_process.txt): 1 = the training-mode forward and the backward finalize inside their
+// apply pass (fold + apply), 0 = fold (long lists) + finalize launch + apply as in round 2.
+int g_bn_fused_finalize = 0;
+
+struct BnWs { float* partial; float* coef; double* folded; size_t bytes; };
 template <int VEC> BnWs bn_ws(void* base, int64_t M, int C) {
     BnGeom g = bn_geom<VEC>(M, C);
     BnWs w;
     const size_t pbytes = dir_align_up(sizeof(float) * (size_t)g.rblocks * 2 * C, 256);
+    const size_t cbytes = dir_align_up(sizeof(float) * 3 * (size_t)C, 256);
     w.partial = reinterpret_cast<float*>(base);
     w.coef = reinterpret_cast<float*>(static_cast<char*>(base) + pbytes);
-    w.bytes = pbytes + dir_align_up(sizeof(float) * 3 * (size_t)C, 256);
+    w.folded = reinterpret_cast<double*>(static_cast<char*>(base) + pbytes + cbytes);     // [BN_FOLD_ROWS][2][C] float64
+    w.bytes = pbytes + cbytes + dir_align_up(sizeof(double) * BN_FOLD_ROWS * 2 * (size_t)C, 256);
     return w;
+}
+
+// partial list [rows][2][C] (float) -> <= BN_FOLD_ROWS rows of float64 in `folded`; returns the folded row count
+int bn_fold(const float* part, int rows, int C, double* folded, hipStream_t s) {
+    int splits = rows / 48;                                          // >= 48 rows per fold workgroup
+    if (splits > BN_FOLD_ROWS) splits = BN_FOLD_ROWS;
+    if (splits < 1) splits = 1;
+    const int rps = dir_cdiv(rows, splits);
+    splits = dir_cdiv(rows, rps);
+    hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3(dir_cdiv(C, 8), splits), dim3(DIR_TPB), 0, s, part, rows, C, rps, folded);
+    return splits;
 }
 
 bool bn_shape_ok(int dtype, int64_t M, int C) {
@@ -616,17 +701,17 @@ int prepare_impl(const void* x_, int64_t M, int C, const float* gamma, const flo
 
 template <typename T>
 int apply_impl(const void* x_, const void* res_, const float* rcoef, void* y_, int64_t M, int C, const float* coef, int relu,
-               hipStream_t s, uint8_t* bits = nullptr) {
+               hipStream_t s, uint8_t* bits = nullptr, BnFinF fin = BnFinF{}) {
     constexpr int VEC = Vec<T>::N;
     const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
     BnGeom g = bn_geom<VEC>(M, C);
     const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
-    if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
-    else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
-    else if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
-    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits);
+    if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
+    else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
+    else if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -639,6 +724,22 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
     constexpr int VEC = Vec<T>::N;
     BnWs w = bn_ws<VEC>(ws, M, C);
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
+    if (training && g_bn_fused_finalize) {
+        // statistics (own pass, or the producing convolution's partial list) -> fold to <= BN_FOLD_ROWS float64 rows -> the apply
+        // pass finalizes per channel tile itself (no finalize launch)
+        const float* part = ext_partial;
+        int prow = ext_rows;
+        if (!part) {
+            BnGeom g = bn_geom<VEC>(M, C);
+            hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(g.rblocks, g.ctiles), dim3(DIR_TPB), 0, s, static_cast<const T*>(x_), M, C, g, w.partial);
+            DIR_LAUNCH_CHECK();
+            part = w.partial; prow = g.rblocks;
+        }
+        const int frows = bn_fold(part, prow, C, w.folded, s);
+        DIR_LAUNCH_CHECK();
+        const BnFinF fin{w.folded, frows, (double)M, momentum, eps, gamma, beta, running_mean, running_var, save_mean, save_rstd};
+        return apply_impl<T>(x_, res_, nullptr, y_, M, C, nullptr, relu, s, bits, fin);
+    }
     if (training) {
         const int rc = prepare_impl<T>(x_, M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
                                        w.coef, ws, ws_bytes, s, ext_partial, ext_rows);
@@ -664,7 +765,22 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     const BnMaskCoef mc{gamma, beta, save_mean, save_rstd};
     // mask source: saved output if given, else recomputed from x (only valid when no residual was added)
     const int mask = !relu ? 0 : (out ? 1 : 2);
-    if (ext_partial) {
+    BnFinB fin{};
+    if (g_bn_fused_finalize) {
+        const float* part = ext_partial;
+        int prow = ext_rows;
+        if (part) { DIR_RETURN_IF(mask == 1, DIR_EINVAL); }
+        else {
+            if (mask == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 1>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+            else if (mask == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 2>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+            else hipLaunchKernelGGL((bn_bwd_partial_kernel<T, 0>), grid, blk, 0, s, dout, x, out, M, C, g, w.partial, mc);
+            DIR_LAUNCH_CHECK();
+            part = w.partial; prow = g.rblocks;
+        }
+        const int frows = bn_fold(part, prow, C, w.folded, s);
+        DIR_LAUNCH_CHECK();
+        fin = BnFinB{w.folded, frows, (double)M, gamma, save_mean, save_rstd, dgamma, dbeta};
+    } else if (ext_partial) {
         // the first pass ran inside the data-gradient kernel that produced dout (dir_conv_dgrad_bnstats): one row of partials per
         // 128-pixel tile; long lists are folded to <= 32 rows of doubles first (as in the forward, prepare_impl)
         DIR_RETURN_IF(mask == 1, DIR_EINVAL);
@@ -693,11 +809,11 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
                            save_mean, save_rstd, dgamma, dbeta, w.coef);
         DIR_LAUNCH_CHECK();
     }
-    if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
-    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
-    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc);
+    if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
+    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -744,6 +860,8 @@ extern "C" int dir_bn_bwd_join(const void* g, const void* x, const void* r, void
     return bwd_join_impl<float>(g, x, r, dx, dr, M, C, gamma, save_mean, save_rstd, gamma_r, save_mean_r, save_rstd_r, dgamma, dbeta,
                                 dgamma_r, dbeta_r, workspace, workspace_bytes, dir_s(stream));
 }
+
+extern "C" int dir_bn_set_fused_finalize(int mode) { const int prev = g_bn_fused_finalize; g_bn_fused_finalize = mode ? 1 : 0; return prev; }
 
 extern "C" size_t dir_bn_workspace(int dtype, int64_t M, int C) {
     if (!bn_shape_ok(dtype, M, C)) return 0;

@@ -212,6 +212,10 @@ int dir_lds_weights(const double* labels, int64_t n, int max_target, int reweigh
  * workspace: >= dir_bn_workspace(dtype, M, C) bytes (0 = unsupported shape), 256-byte aligned.
  */
 size_t dir_bn_workspace(int dtype, int64_t M, int C);
+/* A/B switch for tools and tests (process-wide, default 0 — measured neutral): 1 = the training-mode forward and the backward compute their per-channel
+ * coefficients INSIDE the apply pass (fold of the partial list + apply: no finalize launch), 0 = fold + finalize + apply (round 2).
+ * Returns the previous setting. */
+int dir_bn_set_fused_finalize(int mode);
 int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      double momentum, double eps, int relu, float* save_mean, float* save_rstd,
