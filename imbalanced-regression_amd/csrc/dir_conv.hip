@@ -23,6 +23,7 @@
 // 24 LDS and 8 buffer instructions and ~16 VALU instructions.
 // Workgroup ids are remapped so that the N-tiles of one M-tile run on the same XCD (A tile re-reads hit that L2).
 #include <cstdlib>
+#include <type_traits>
 #include "dir_common.h"
 #include "dir_conv_shared.h"
 
@@ -935,6 +936,162 @@ conv3x3_patch_kernel(ConvP p) {
     cv_epilogue<BN, false, NST == 1 ? 4 : 2>(pe, acc, smem, t, m0, n0, mt);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels on 56^2 maps (conv2 of stage 1, and its data gradient), WEIGHTS RESIDENT:
+// these three layers (x forward, data gradient and epoch-tail forward) sat furthest from their roofline (108 / 90 us against
+// 34 us of HBM time): a patch-staged workgroup does 72 MFMAs per wavefront between a patch load, NINE weight-slice round trips
+// (8 KB each, one barrier pair per tap) and a store drain — 7168 workgroups whose latency chains four co-resident workgroups only
+// partly hide. Here ONE persistent workgroup per CU keeps all nine taps of the 64 x 64 weights in LDS (72 KB, loaded once), walks
+// its chunks of two image rows, and per chunk does: [patch of chunk j has landed] -> barrier -> DMA of chunk j + 1's patch into the
+// other patch buffer -> 9 taps x 8 MFMAs straight out of LDS (no weight traffic, no per-tap barrier) -> epilogue of chunk j.
+// The next patch's DMA is issued BEFORE the epilogue's stores, so the counted vmcnt wait that precedes the next chunk's MFMAs
+// covers the DMA and not the stores (gfx950 retires loads and stores through ONE in-order counter): nothing ever waits for a
+// store to be acknowledged. Same MFMA order per output element as conv3x3_patch_kernel: bit-identical results and statistics.
+// LDS: weights 73 728 + two patch buffers 65 536 + the epilogue's staging tile and column partials 20 480 = 159 744 bytes.
+template <bool LEAN>
+__global__ void __launch_bounds__(DIR_TPB)
+conv3x3_resident_kernel(ConvP p, int nchunks) {
+    using G = CpGeom<56>;
+    constexpr int BN = 64, MI = 1, NI = 2, WM = 32, B_BYTES = BN * CV_ROWB;
+    constexpr int W_BYTES = 9 * B_BYTES;                          // 73 728
+    // vmcnt is per wavefront and in issue order: behind the next patch's DMA every wavefront issues the epilogue's row stores — 4
+    // (CV_BM / (DIR_TPB / 8)), or 3 for the wavefronts whose last row lies in the tile's padding (rows 112..127: the lean store
+    // loop skips the instruction) — and wavefronts 0-1 one statistics store. Waiting for "all but the newest 3" therefore covers
+    // the DMA for every wavefront and never a store that has not been issued long ago.
+    constexpr int NSTORE = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Wres = smem;
+    unsigned char* Pat = smem + W_BYTES;
+    unsigned char* Stage = smem + W_BYTES + 2 * G::PATCH;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    typedef __attribute__((address_space(3))) unsigned char* cp_lds_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(cp_lds_t)smem;
+    const cp_u32x4 rs_x = cp_rsrc(p.x, (uint32_t)(p.N * p.H * p.W) * (uint32_t)p.Cin * 2u);
+    const int K = p.KT * CV_BK;
+    const cp_u32x4 rs_w = cp_rsrc(p.w, (uint32_t)p.Cout * (uint32_t)K * 2u);
+    const int lr = lane >> 3, lc = lane & 7;
+
+    // ---- the nine weight slices, once: piece i of this wave = rows wave*16 + 8 i + lr of tap `tap` (as CP_ISSUE_B)
+    {
+        int woff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+            woff[i] = ((wave * 16 + 8 * i + lr) * K + chunk * 8) * 2;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                cp_dma16(rs_w, lds0 + (uint32_t)(tap * B_BYTES + wave * 2048 + i * 1024), woff[i], tap * CV_BK * 2);
+    }
+    // ---- per-lane patch roles and fragment addresses (chunk independent)
+    int prel[G::PPW];                                             // source chunk of the lane relative to pixel (h0 - 1, -1); CV_OOB = border
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) {
+        const int q = wave + 4 * i;
+        const int row = q * 8 + lr;
+        const int pr = row / G::P, pc = row - pr * G::P;
+        prel[i] = (pc >= 1 && pc <= 56) ? ((pr * 56 + pc) * 64 + (lc ^ ((row >> 1) & 7)) * 8) * 2 : CV_OOB;   // (rows outside the image: below)
+    }
+    uint32_t arow[3], az[3];
+    {
+        const int k = wm * WM + frow;
+        const int i = k / 56, w = k - i * 56;
+        const int pp0 = k < G::KPIX ? i * G::P + w : 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) { arow[s2] = (uint32_t)(pp0 + s2) * CV_ROWB; az[s2] = (uint32_t)(((pp0 + s2) >> 1) & 7); }
+    }
+    uint32_t bf[NI][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = ni * 32 + frow;
+            bf[ni][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+        }
+    // patch rows pr = 0 / 3 fall outside the image for the first / last chunk of an image: those pieces load zeros
+    auto issue_patch = [&](int chunk, int ps) {
+        const int n_img = chunk / G::CPI, h0 = (chunk - n_img * G::CPI) * G::RB;
+        const int xbase = (((n_img * 56 + h0 - 1) * 56 - 1) * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int q = wave + 4 * i;
+            const int pr = (q * 8) / G::P;                        // (a piece never straddles patch rows: P = 64 is a multiple of 8)
+            const int hi = h0 - 1 + pr;
+            const bool in = prel[i] != CV_OOB && hi >= 0 && hi < 56;
+            cp_dma16(rs_x, lds0 + (uint32_t)(W_BYTES + ps * G::PATCH + q * 1024), in ? xbase + prel[i] : CV_OOB, 0);
+        }
+    };
+    const int first = blockIdx.x, step = gridDim.x;
+    if (first >= nchunks) { cp_dma_wait(); return; }
+    issue_patch(first, 0);
+    f32x16 acc[MI][NI];
+    int ps = 0;
+    for (int chunk = first; chunk < nchunks; chunk += step) {
+        // patch `chunk` (and, the first time, the weights) has landed for this wave: everything older than the previous chunk's
+        // NSTORE row stores (+ the statistics store) — those stay in flight
+        if (chunk == first) cp_dma_wait();
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORE - 1) : "memory");
+        __syncthreads();                                          // ... for everybody; the other patch buffer and the staging tile are free
+        if (chunk + step < nchunks) issue_patch(chunk + step, ps ^ 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+        // One wavefront per SIMD: nobody else hides the LDS latency of the fragment reads, so they are software-pipelined by hand —
+        // the twelve fragments of tap t + 1 are read (into the other register set) before the eight MFMAs of tap t are issued.
+        const unsigned char* pb = Pat + ps * G::PATCH;
+        bf16x8 fa[2][4], fb[2][NI][4];
+        auto read_tap = [&](auto tap_c, auto set_c) {
+            constexpr int tap = decltype(tap_c)::value, set = decltype(set_c)::value;
+            constexpr int r_ = tap / 3, s_ = tap % 3;
+            const unsigned char* ab = pb + r_ * (G::P * CV_ROWB);
+            const unsigned char* bbs = Wres + tap * B_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                fa[set][kk] = *reinterpret_cast<const bf16x8*>(ab + arow[s_] + ((((uint32_t)(kk * 2 + fhalf)) ^ az[s_]) << 4));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[set][ni][kk] = *reinterpret_cast<const bf16x8*>(bbs + bf[ni][kk]);
+            }
+        };
+        auto mfma_tap = [&](auto set_c) {
+            constexpr int set = decltype(set_c)::value;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][ni][kk], fa[set][kk], acc[0][ni], 0, 0, 0);
+        };
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+#define RS_TAP(T_) std::integral_constant<int, T_>{}
+#define RS_SB __builtin_amdgcn_sched_barrier(0)          /* pins "reads of tap t + 1, then MFMAs of tap t" (the scheduler otherwise sinks the reads) */
+        read_tap(RS_TAP(0), I0{}); RS_SB;
+        read_tap(RS_TAP(1), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
+        read_tap(RS_TAP(2), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
+        read_tap(RS_TAP(3), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
+        read_tap(RS_TAP(4), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
+        read_tap(RS_TAP(5), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
+        read_tap(RS_TAP(6), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
+        read_tap(RS_TAP(7), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
+        read_tap(RS_TAP(8), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
+        mfma_tap(I0{});
+#undef RS_SB
+#undef RS_TAP
+        const int n_img = chunk / G::CPI, h0 = (chunk - n_img * G::CPI) * G::RB;
+        const int m0 = (n_img * 56 + h0) * 56;
+        ConvP pe = p;
+        pe.M = m0 + G::KPIX;                                      // rows past the chunk's pixels are padding: not stored, not counted
+        cv_epilogue<BN, LEAN, 4>(pe, acc, Stage, t, m0, 0, chunk);
+        ps ^= 1;
+    }
+}
+
 template <int WI> constexpr int cp_chunks_per_image() { return CpGeom<WI>::CPI; }
 
 }  // namespace
@@ -953,8 +1110,10 @@ static int cp_chunks(int W) { return W == 56 ? 28 : W == 28 ? 7 : 2; }
 // A/B switch for tools and tests (process-wide, default 1): 0 = those layers take the per-tap kernels again, 1 = patch-staged,
 // single LDS stage (four workgroups per CU), 2 = patch-staged, two stages (two per CU; measured 0.16 ms per step slower). Returns the
 // previous setting. Changes dir_conv_tile_rows accordingly — flip it only between whole forward/backward passes.
+// 3 = 1 + the 64 -> 64 channel layers on 56^2 maps run conv3x3_resident_kernel (persistent, weights resident in LDS): measured equal
+// to mode 1 in isolation (114.6 vs 108.4 us forward, 85.7 vs 87.9 us data gradient) and +1.2 % on the training step, so NOT the default.
 static int g_patch3x3 = 1;
-extern "C" int dir_conv_set_patch3x3(int mode) { const int prev = g_patch3x3; g_patch3x3 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return prev; }
+extern "C" int dir_conv_set_patch3x3(int mode) { const int prev = g_patch3x3; g_patch3x3 = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return prev; }
 static int g_patch3x3_on() { return g_patch3x3; }
 
 // Rows of the per-tile statistics / BatchNorm-partial list of ONE launch with this geometry (the tiling depends on the kernel
@@ -1130,6 +1289,25 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     if (cpw) {
         // patch-staged 3x3: M tiles = chunks of whole image rows
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
+        if (cpw == 56 && Cin == 64 && Cout == 64 && g_patch3x3 == 3 && variant != 3 && !(p.addend && p.addend2)) {
+            // stage 1's conv2 (and its data gradient): persistent workgroups with all nine taps of the weights resident in LDS
+            const int nchunks = N * cp_chunks(56);
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0; hipDeviceProp_t prop;
+                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            const int grid = nchunks < cus ? nchunks : cus;
+            constexpr int lds_res = 9 * 64 * CV_ROWB + 2 * 256 * CV_ROWB + CV_BM * (64 * 2 + 16) + 4 * 2 * 64 * 4;     // 159 744
+            static bool once_res = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_res),
+                                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_res), true);
+            (void)once_res;
+            const bool lean3 = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
+            if (lean3) hipLaunchKernelGGL(conv3x3_resident_kernel<true>, dim3(grid), dim3(DIR_TPB), lds_res, s, p, nchunks);
+            else hipLaunchKernelGGL(conv3x3_resident_kernel<false>, dim3(grid), dim3(DIR_TPB), lds_res, s, p, nchunks);
+            DIR_LAUNCH_CHECK();
+            return DIR_OK;
+        }
         const int nst = g_patch3x3 == 2 ? 2 : 1;                        // default: single stage, four workgroups per CU
         const int npatch = (nst == 2 && p.cpk > 1) ? 2 : 1;
         const int prows = cpw == 56 ? 256 : cpw == 28 ? 192 : 144;

@@ -294,7 +294,10 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
 size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
 /* A/B switch for tools and tests (process-wide, default 1): 0 = the 3x3 / stride-1 layers take the per-tap kernels again (and
  * dir_conv_tile_rows answers accordingly), 1 = patch-staged with one LDS stage (four workgroups per CU), 2 = patch-staged with
- * two stages (two per CU).  Returns the previous setting; flip only between whole passes. */
+ * two stages (two per CU), 3 (round-3 experiment, not faster) = 1, and the 64 -> 64 channel layers on 56^2 maps (conv2 of stage 1 and its
+ * data gradient) run persistent workgroups with all nine taps of the weights resident in LDS (conv3x3_resident_kernel: no weight
+ * traffic, no per-tap barrier, the next patch's DMA issued ahead of the stores; bit-identical results and statistics).
+ * Returns the previous setting; flip only between whole passes. */
 int dir_conv_set_patch3x3(int mode);
 /* A/B switch for tools and tests (process-wide, default 0): 1 = launches with Cout % 128 == 0 that are not patch-staged run the
  * persistent ring kernel (csrc/dir_conv_ring.hip: 8 wavefronts per CU with loader / storer roles, LDS-DMA ring across tile
