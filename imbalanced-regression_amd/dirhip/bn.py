@@ -37,12 +37,17 @@ class BwdLink:
     so it also forms the per-channel sums of ``dout`` and ``dout * x`` in its store loop (``dir_conv_dgrad_bnstats``) and
     leaves them in ``partial``; the BatchNorm backward then runs without its reduction pass (``dir_bn_bwd_partials``).
     ``needs_relu_claim``: the BatchNorm output went through ``relu(. + residual)``, so the sums are only right when the
-    consumer also applies that ReLU's backward (``defer_relu_grad`` claimed)."""
-    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "recompute_mask", "needs_relu_claim", "partial")
+    consumer also applies that ReLU's backward (``defer_relu_grad`` claimed).
+    CONTRACT (checked where it is cheap): the BatchNorm output has exactly ONE consumer and that consumer's backward runs first; it
+    records the storage address of the gradient tensor it wrote (``dout_ptr``) next to ``partial``, and the BatchNorm backward takes
+    the sums only if the ``dout`` autograd hands it IS that tensor — if anything else contributed to the gradient (an auxiliary
+    head, a hook, another wiring of the block) autograd has summed into a new tensor and the reduction pass runs as usual."""
+    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "recompute_mask", "needs_relu_claim", "partial", "dout_ptr")
 
     def __init__(self):
         self.x = self.gamma = self.beta = self.mean = self.rstd = self.partial = None
         self.recompute_mask = self.needs_relu_claim = False
+        self.dout_ptr = None
 
 
 class _BNActFn(torch.autograd.Function):
@@ -125,6 +130,8 @@ class _BNActFn(torch.autograd.Function):
         ws = _ws(code, m, c, x.device)
         link = getattr(ctx, "link", None)
         part = None if link is None else link.partial
+        if part is not None and link.dout_ptr != dout.data_ptr():
+            part, link.partial = None, None                  # the sums are of another tensor than the gradient we were handed
         if part is not None and dres is None and y is None:
             # the consumer's data-gradient kernel already summed dout and dout * x per channel (BwdLink): finalize + apply only
             link.partial = None

@@ -22,10 +22,15 @@ def supported(cin, cout, x=None):
     if cin % 64 or cout % 64:
         return False
     if x is not None:
-        rows = x.shape[0] * x.shape[2] * x.shape[3]
-        if rows >= (1 << 24) or rows * max(cin, cout) >= (1 << 30):
-            return False
+        return rows_supported(cin, cout, x.shape[0] * x.shape[2] * x.shape[3])
     return True
+
+
+def rows_supported(cin, cout, rows):
+    """The 32-bit-offset limits of ``dir_conv_fwd`` / its data gradient for a layer whose LARGER side (input or output map) has
+    ``rows`` = N*H*W pixels: rows < 2^24 and rows * max(Cin, Cout) < 2^30 elements (the kernel itself refuses at N*H*W*Cin >= 2^30 /
+    M*Cout >= 2^31 with DIR_EUNSUPPORTED; this is the conservative host-side twin that selects the float32 fallback first)."""
+    return rows < (1 << 24) and rows * max(cin, cout) < (1 << 30)
 
 
 def _bn_link_args(link):
@@ -83,6 +88,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
                 "dir_conv_dgrad_ex")
         if bn_link is not None:
             bn_link.partial = part
+            bn_link.dout_ptr = y.data_ptr()
         return y
     if addend_s2 is not None:
         L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
@@ -198,6 +204,7 @@ class _ConvFn(torch.autograd.Function):
                                                           *_bn_link_args(link), L.ptr(part), L.stream_ptr(x.device)),
                         "dir_conv_dgrad_s2_bnstats")
                 link.partial = part
+                link.dout_ptr = dx.data_ptr()
             else:
                 L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
                                                   L.stream_ptr(x.device)), "dir_conv_dgrad_s2")

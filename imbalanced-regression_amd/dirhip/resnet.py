@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .bn import BatchCounters, bn_act, bn_join
-from .conv import conv_bn_input, projection_pair, projection_pair_ok, stem_conv, stem_conv_ok, supported as _igemm_ok
+from .conv import conv_bn_input, projection_pair, projection_pair_ok, rows_supported, stem_conv, stem_conv_ok, supported as _igemm_ok
 from .conv_f32 import conv_f32, conv_ok
 from .fds import FDS
 from .pool import bn_relu_maxpool, global_avgpool_flat, maxpool3x3s2
@@ -101,7 +101,11 @@ class Bottleneck(nn.Module):
         fused = _fusable(x)
         if fused and self.downsample is not None and self.bn3.training and self.downsample[1].training \
                 and projection_pair_ok(self.conv1, self.downsample[0], x) \
-                and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) and (x.shape[2] | x.shape[3]) % 2 == 0:
+                and _igemm_ok(self.conv3.in_channels, self.conv3.out_channels) and (x.shape[2] | x.shape[3]) % 2 == 0 \
+                and rows_supported(self.conv3.in_channels, self.conv3.out_channels,
+                                   x.shape[0] * (x.shape[2] // self.stride) * (x.shape[3] // self.stride)):
+            # (conv3 is called through conv_bn_input without the fallback of _conv_bn: its 4x wider output — and the gradient its data
+            # gradient reads — must fit the kernel's 32-bit offsets too, else the block takes the general path below)
             # projection block: conv1 and the downsample conv are one node (their data gradients and the previous
             # block's ReLU backward meet inside one kernel, the stride-2 gradient in compact form), and
             # relu(bn3(conv3(.)) + bn_d(conv_d(x))) is one join with both normalisations in ONE apply pass
