@@ -179,16 +179,92 @@ def gen_b256_emul32():
     print(f"b256 emul32: loss {loss32.item():.9f}  ({time.time() - t0:.0f} s)")
 
 
+MULTI = dict(seed_model=51, seed_x=52, seed_lab=53, seed_fds=54, batch=32, n_fds=4000, steps=4, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+
+
+def multistep_inputs(c):
+    g = torch.Generator().manual_seed(c["seed_x"])
+    xs = [torch.randn(c["batch"], 3, 224, 224, generator=g) for _ in range(c["steps"])]
+    x_eval = torch.randn(16, 3, 224, 224, generator=g)
+    rng = np.random.default_rng(c["seed_lab"])
+    ys = [torch.tensor(r2.long_tail(rng, c["batch"])).view(-1, 1) for _ in range(c["steps"])]
+    ws = [torch.tensor(rng.uniform(0.5, 1.5, c["batch"]).astype(np.float32)).view(-1, 1) for _ in range(c["steps"])]
+    rounds = []
+    for ep in range(2):
+        rr = np.random.default_rng(c["seed_fds"] + ep)
+        lab = r2.long_tail(rr, c["n_fds"])
+        feats = (np.abs(rr.normal(0, 1, (c["n_fds"], 2048))) * 0.5 + 0.01 * lab[:, None]).astype(np.float32)
+        rounds.append((torch.tensor(feats), torch.tensor(lab)))
+    return xs, ys, ws, x_eval, rounds
+
+
+def gen_multistep():
+    """multistep_b32.npz: FOUR optimizer steps of the reference (train.py:246-262: resnet50 + live FDS calibration + weighted_l1_loss +
+    SGD with momentum and weight decay, lr 1e-3 — steps small enough that float32 round-off does not decide the trajectory), then
+    an eval-mode forward of a held-out batch (BatchNorm running statistics of all four steps in use) and the epoch tail on the
+    last batch: pins the interplay of the optimizer, the bf16/float32 weight caches, BatchNorm running statistics and FDS over
+    several steps, not just step 0. Run in float32 (the reference) and float64 (what float32 can resolve)."""
+    c = MULTI
+    ref = refshim.load("imdb-wiki-dir")
+    xs, ys, ws, x_eval, rounds = multistep_inputs(c)
+    out = {}
+    for dtype, tag in ((torch.float32, "ref"), (torch.float64, "ref64")):
+        torch.manual_seed(c["seed_model"])
+        model = refshim.make_resnet50("imdb-wiki-dir", fds=True, **FDS_KW)
+        with refshim.cuda_identity():
+            for ep, (f, l) in enumerate(rounds):
+                model.FDS.update_last_epoch_stats(ep)
+                model.FDS.update_running_stats(f, l, ep)
+        if dtype != torch.float32:
+            model = model.to(dtype)
+            model.FDS.kernel_window = model.FDS.kernel_window.to(dtype)
+        opt = torch.optim.SGD(model.parameters(), lr=c["lr"], momentum=c["momentum"], weight_decay=c["weight_decay"])
+        losses = []
+        model.train()
+        for x, y, w in zip(xs, ys, ws):
+            with refshim.cuda_identity():
+                pred, enc = model(x.to(dtype), y.to(dtype), 2)
+            loss = ref.loss.weighted_l1_loss(pred, y.to(dtype), w.to(dtype))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        with torch.no_grad(), refshim.cuda_identity():                      # train.py:269-281 on the last batch
+            _, feat = model(xs[-1].to(dtype), ys[-1].to(dtype), 2)
+            model.FDS.update_last_epoch_stats(2)
+            model.FDS.update_running_stats(feat.squeeze().float() if dtype == torch.float32 else feat.squeeze(), ys[-1].squeeze().to(dtype), 2)
+        model.eval()
+        with torch.no_grad():
+            pe = model(x_eval.to(dtype))
+        out[f"{tag}_losses"] = np.array(losses, dtype=np.float64)
+        out[f"{tag}_pred_eval"] = pe.double().numpy()
+        out[f"{tag}_bn1_running_mean"] = model.bn1.running_mean.double().numpy()
+        out[f"{tag}_bn1_running_var"] = model.bn1.running_var.double().numpy()
+        out[f"{tag}_l3_bn2_running_var"] = model.layer3[2].bn2.running_var.double().numpy()
+        out[f"{tag}_l4_bn3_running_mean"] = model.layer4[2].bn3.running_mean.double().numpy()
+        out[f"{tag}_linear_weight"] = model.linear.weight.detach().double().numpy()
+        out[f"{tag}_l1_conv1_weight_sample"] = model.layer1[0].conv1.weight.detach().double().reshape(-1)[:512].numpy()
+        out[f"{tag}_fds_tracked"] = model.FDS.num_samples_tracked.double().numpy()
+        out[f"{tag}_fds_running_mean_sum"] = np.array(float(model.FDS.running_mean.double().sum()))
+        print(tag, losses, flush=True)
+    out["in_labels"] = np.stack([y.numpy() for y in ys])
+    out["in_weights"] = np.stack([w.numpy() for w in ws])
+    out["config"] = np.array(json.dumps(dict(c, **FDS_KW)))
+    np.savez_compressed(os.path.join(HERE, "multistep_b32.npz"), **out)
+
+
 def main():
-    which = sys.argv[1:] or ["b64emul", "b256", "b256emul32"]
+    which = sys.argv[1:] or ["b64emul", "b256", "b256emul32", "multistep"]
     if "b64emul" in which:
         gen_b64_emul()
     if "b256" in which:
         gen_b256()
     if "b256emul32" in which:
         gen_b256_emul32()
+    if "multistep" in which:
+        gen_multistep()
     manifest = {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
-                "files": ["step0_b64_bf16emul.npz", "step0_b256.npz"], "generator": "tests/golden/gen_golden_r3.py"}
+                "files": ["step0_b64_bf16emul.npz", "step0_b256.npz", "multistep_b32.npz"], "generator": "tests/golden/gen_golden_r3.py"}
     with open(os.path.join(HERE, "MANIFEST_r3.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 
