@@ -89,7 +89,8 @@ def build(args, device, rank):
                      kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
     engine = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
     engine.train()
-    optimizer = torch.optim.Adam(engine.parameters(), lr=1e-3, fused=True)
+    from dirhip.optim import Adam
+    optimizer = Adam(engine.parameters(), lr=1e-3)          # torch.optim.Adam's arithmetic and state, one HIP launch (+ the bf16 weight operands)
     # ---- LDS weights: native host routine on the synthetic train-label set (identical on every rank)
     rng_all = np.random.default_rng(1)
     all_labels = long_tail_labels(rng_all, N_TRAIN)

@@ -1397,14 +1397,33 @@ __device__ __forceinline__ size_t conv_prep_rot_index(int rot_mode, int ci, int 
     return (size_t)base * Cin * Cout + ((size_t)ci * taps + t) * Cout + co;
 }
 
-__device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int Cout, int RS, int Cin,
-                                               uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot, int rot_mode) {
+// Adam (torch.optim.Adam's single-tensor arithmetic, no amsgrad): one element; returns the new parameter value
+struct AdamH { float step_size, beta2, one_minus_beta1, one_minus_beta2, eps, weight_decay, bias_correction2_sqrt; };   // (host: float64, then rounded, like torch's Python scalars)
+__device__ __forceinline__ float adam_update(float p, float g, float* __restrict__ m, float* __restrict__ v, size_t i, const AdamH& h) {
+    if (h.weight_decay != 0.0f) g = g + h.weight_decay * p;                      // grad.add(param, alpha=weight_decay)
+    const float m0 = m[i], v0 = v[i];
+    const float m1 = m0 + h.one_minus_beta1 * (g - m0);                           // exp_avg.lerp_(grad, 1 - beta1)
+    const float v1 = v0 * h.beta2 + h.one_minus_beta2 * (g * g);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    m[i] = m1; v[i] = v1;
+    const float denom = sqrtf(v1) / h.bias_correction2_sqrt + h.eps;              // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    return p - h.step_size * (m1 / denom);                                        // param.addcdiv_(exp_avg, denom, value=-step_size), step_size = lr / bias_correction1
+}
+
+// ADAM: w is first UPDATED in place from (g, m, v) — the optimizer step — and the bf16 operands are made from the new value in the
+// same pass (dir_adam_step): one read of the master weight for the optimizer and the two layout conversions together.
+template <bool ADAM = false>
+__device__ __forceinline__ void conv_prep_body(float* __restrict__ w, int Cout, int RS, int Cin,
+                                               uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot, int rot_mode,
+                                               const float* __restrict__ g = nullptr, float* __restrict__ m = nullptr,
+                                               float* __restrict__ v = nullptr, AdamH h = AdamH{}) {
     __shared__ uint16_t tile[64][66];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;           // 4 rows of 64 per pass
     if ((Cout & 63) || (Cin & 63)) {                               // generic fallback (not used by ResNet-50's layers)
         const size_t n = (size_t)Cout * RS * Cin;
         for (size_t i = (size_t)blockIdx.x * DIR_TPB + t; i < n; i += (size_t)gridDim.x * DIR_TPB) {
-            const uint16_t h = (uint16_t)cv_f2bf(w[i]);
+            float wv = w[i];
+            if (ADAM) { wv = adam_update(wv, g[i], m, v, i, h); w[i] = wv; }
+            const uint16_t h = (uint16_t)cv_f2bf(wv);
             w16[i] = h;
             if (w16_rot) {
                 const int ci = (int)(i % Cin); const size_t t1 = i / Cin; const int tap = (int)(t1 % RS); const int co = (int)(t1 / RS);
@@ -1419,9 +1438,11 @@ __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int 
 #pragma unroll 4
         for (int r = ty; r < 64; r += 4) {                         // row = output channel, 64 consecutive input channels
             const size_t i = ((size_t)(co0 + r) * RS + tap) * Cin + ci0 + tx;
-            const uint16_t h = (uint16_t)cv_f2bf(w[i]);
-            w16[i] = h;
-            tile[r][tx] = h;
+            float wv = w[i];
+            if (ADAM) { wv = adam_update(wv, g[i], m, v, i, h); w[i] = wv; }
+            const uint16_t hb = (uint16_t)cv_f2bf(wv);
+            w16[i] = hb;
+            tile[r][tx] = hb;
         }
         if (w16_rot) {
             __syncthreads();
@@ -1436,17 +1457,55 @@ __device__ __forceinline__ void conv_prep_body(const float* __restrict__ w, int 
 __global__ void __launch_bounds__(DIR_TPB)
 conv_prep_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, uint16_t* __restrict__ w16,
                          uint16_t* __restrict__ w16_rot, int rot_mode) {
-    conv_prep_body(w, Cout, RS, Cin, w16, w16_rot, rot_mode);
+    conv_prep_body(const_cast<float*>(w), Cout, RS, Cin, w16, w16_rot, rot_mode);
 }
 
 // blockIdx.y = layer; the layer's row of the table holds its pointers and extents
 __global__ void __launch_bounds__(DIR_TPB)
 conv_prep_weights_batched_kernel(const long long* __restrict__ table) {
     const long long* e = table + (size_t)blockIdx.y * 7;
-    conv_prep_body(reinterpret_cast<const float*>(e[0]), (int)e[3], (int)e[4], (int)e[5],
+    conv_prep_body(reinterpret_cast<float*>(e[0]), (int)e[3], (int)e[4], (int)e[5],
                    reinterpret_cast<uint16_t*>(e[1]), reinterpret_cast<uint16_t*>(e[2]), (int)e[6]);
 }
 }  // namespace
+
+namespace {
+// One Adam step for EVERY parameter tensor of the network in one launch (blockIdx.y = tensor; row of the table = 12 int64:
+// param, grad, exp_avg, exp_avg_sq, numel, w16, w16_rot, Cout, RS, Cin, rot_mode, 0). Rows with w16 != 0 are convolution weights:
+// their bf16 operands for the next forward / data gradient are rewritten from the updated value in the same pass.
+__global__ void __launch_bounds__(DIR_TPB)
+adam_step_kernel(const long long* __restrict__ table, AdamH h) {
+    const long long* e = table + (size_t)blockIdx.y * 12;
+    float* w = reinterpret_cast<float*>(e[0]);
+    const float* g = reinterpret_cast<const float*>(e[1]);
+    float* m = reinterpret_cast<float*>(e[2]);
+    float* v = reinterpret_cast<float*>(e[3]);
+    if (e[5]) {
+        conv_prep_body<true>(w, (int)e[7], (int)e[8], (int)e[9], reinterpret_cast<uint16_t*>(e[5]), reinterpret_cast<uint16_t*>(e[6]), (int)e[10], g, m, v, h);
+        return;
+    }
+    const size_t n = (size_t)e[4];
+    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * DIR_TPB)
+        w[i] = adam_update(w[i], g[i], m, v, i, h);
+}
+}  // namespace
+
+// torch.optim.Adam.step() (train.py:161-162 builds the optimizer, :259-260 steps it) for all parameters in ONE launch, fused with
+// the bf16 weight preparation of the convolution layers (dir_conv_prep_weights_batched). table: device [ntensors][12] int64 (see
+// adam_step_kernel); step >= 1 is the step count AFTER the increment (bias corrections 1 - beta^step, computed on the host in
+// float64 like torch's non-capturable path). float32 parameters, gradients and state, all dense.
+extern "C" int dir_adam_step(const void* table, int ntensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+                             long long step, dir_stream_t stream) {
+    DIR_RETURN_IF(!table || ntensors <= 0 || ntensors > 65535 || step < 1, DIR_EINVAL);
+    AdamH h;
+    h.beta2 = (float)beta2; h.one_minus_beta1 = (float)(1.0 - beta1); h.one_minus_beta2 = (float)(1.0 - beta2);
+    h.eps = (float)eps; h.weight_decay = (float)weight_decay;
+    h.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    h.bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_step_kernel, dim3(128, ntensors), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const long long*>(table), h);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
 
 extern "C" int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t stream) {
     DIR_RETURN_IF(!table || nlayers <= 0 || nlayers > 65535, DIR_EINVAL);

@@ -347,6 +347,31 @@ def _refresh_all(device):
         st.key = _weight_key(w)
 
 
+def prepared_operands(device):
+    """{master weight address: _PreparedWeights} of the live conv layers on ``device`` whose bf16 operands the optimizer kernel may
+    rewrite itself (``dirhip.optim.Adam``): float32 channels_last weights of the registered layers."""
+    out = {}
+    for st in _REGISTRY.get(device, []):
+        conv = st.conv_ref()
+        if conv is None:
+            continue
+        w = conv.weight
+        if w.device == device and w.dtype == torch.float32 and w.is_contiguous(memory_format=torch.channels_last) \
+                and tuple(w.shape) == (st.shape[0], st.shape[2]) + tuple(conv.kernel_size):
+            out[w.data_ptr()] = st
+    return out
+
+
+def mark_prepared_after_step(entries):
+    """The optimizer kernel has just rewritten these layers' bf16 operands from the updated weights: they are valid for the generation
+    the step's post hook (``invalidate_weight_cache``) is about to open."""
+    for st in entries:
+        conv = st.conv_ref()
+        if conv is not None:
+            w = conv.weight
+            st.key = (_GENERATION[0] + 1, w._version, w.data_ptr())
+
+
 def _prepared(conv):
     """bf16 operands of ``conv.weight``, valid for the current optimizer generation."""
     w = conv.weight

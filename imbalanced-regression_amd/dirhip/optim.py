@@ -1,0 +1,89 @@
+"""``Adam`` — drop-in for the ``torch.optim.Adam`` that ``imdb-wiki-dir/train.py:161-162`` builds (same constructor keywords, same
+``state_dict`` layout: ``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so reference optimizer checkpoints load and save).
+
+``step()`` runs ONE hand-written HIP launch for all parameter tensors (``dir_adam_step``: torch's single-tensor Adam arithmetic) and
+rewrites, in the same pass, the bf16 operands of every convolution weight the MFMA kernels will read in the next forward / data
+gradient — the work of torch's multi-tensor fused Adam (5 launches) + ``dir_conv_prep_weights_batched`` before. Anything the
+kernel does not take (amsgrad, maximize, CPU / non-float32 / non-dense parameters, a differentiable step) goes to
+``torch.optim.Adam``'s own ``step`` — there is no silent change of arithmetic.
+"""
+import torch
+
+from . import _lib as L
+from . import conv as _conv
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        kw.pop("fused", None)
+        kw.pop("foreach", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=False, fused=False, **kw)
+        self._tables = {}                  # group index -> (key, device table)
+
+    def _ours(self, group, params):
+        if group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or group.get("capturable"):
+            return False
+        if isinstance(group["lr"], torch.Tensor):
+            return False
+        dev = params[0].device
+        for p in params:
+            g = p.grad
+            if not (p.is_cuda and p.device == dev and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse):
+                return False
+            if p.stride() != g.stride() or not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if not self._ours(group, params):
+                return super().step(None) if loss is None else loss        # torch's own step for every group (never a mix)
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            step = None
+            for p in params:
+                st = self.state[p]
+                if len(st) == 0:                                            # torch's lazy state initialisation (adam.py: _init_group)
+                    st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                s = int(st["step"])
+                if step is None:
+                    step = s
+                elif s != step:
+                    raise L.DirHipError("dirhip.optim.Adam: parameters of one group with different step counts")
+            dev = params[0].device
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+            cached = self._tables.get(gi)
+            if cached is None or cached[0] != key:
+                prepared = _conv.prepared_operands(dev)                     # master-weight address -> the layer's bf16 operand buffers
+                rows = []
+                for p in params:
+                    st = self.state[p]
+                    pw = prepared.get(p.data_ptr())
+                    if pw is not None and not p.is_contiguous(memory_format=torch.channels_last):
+                        pw = None
+                    if pw is None:
+                        rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, 0])
+                    else:
+                        cout, rs, cin = pw.shape
+                        rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), pw.w16.data_ptr(),
+                                     0 if pw.w16_rot is None else pw.w16_rot.data_ptr(), cout, rs, cin, pw.rot_mode, 0])
+                cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), [prepared.get(p.data_ptr()) for p in params])
+                self._tables[gi] = cached
+            b1, b2 = group["betas"]
+            L.check(L.lib().dir_adam_step(L.ptr(cached[1]), len(params), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                          float(group["weight_decay"]), step, L.stream_ptr(dev)), "dir_adam_step")
+            _conv.mark_prepared_after_step([pw for pw in cached[2] if pw is not None])
+        return loss

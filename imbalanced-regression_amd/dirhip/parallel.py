@@ -115,8 +115,9 @@ class DataParallelEngine(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, inputs, *args, **kwargs):
-        if self.world > 1 and self.training and torch.is_grad_enabled():
-            self._prepare_buckets()
+        if self.training and torch.is_grad_enabled() and (self.world > 1 or inputs.is_cuda):
+            self._prepare_buckets()         # (one process: the buckets are just persistent gradient storage — static addresses for the
+                                            #  optimizer kernel's table, no allocation per gradient and step; no hooks, no collective)
         if self.channels_last and inputs.dim() == 4:
             inputs = inputs.contiguous(memory_format=torch.channels_last)
         if self.amp_dtype is not None:
@@ -153,7 +154,8 @@ class DataParallelEngine(nn.Module):
             for bi, b in enumerate(self._buckets):
                 for pi, p in enumerate(b.params):
                     self._bucket_of[id(p)] = (bi, pi)
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+                    if self.world > 1:
+                        self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
                     gradsink.register(p, lambda b=b, pi=pi: b.fresh_view(pi))     # the gradient kernels write into the bucket
             self._signature = sig
         for b in self._buckets:

@@ -26,6 +26,7 @@ from scipy.stats import gmean
 from .parallel import DataParallelEngine, init_distributed, shard_indices
 from .resnet import resnet50
 from .train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
+from .optim import Adam
 from .utils import AverageMeter, ProgressMeter, adjust_learning_rate, prepare_folders, save_checkpoint
 
 print = logging.info
@@ -350,7 +351,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
     parameters = list(filter(lambda p: p.requires_grad, model.parameters()))
     if args.retrain_fc:
         assert 1 <= len(parameters) <= 2  # fc.weight, fc.bias
-    optimizer = torch.optim.Adam(parameters, lr=args.lr, fused=True) if args.optimizer == 'adam' else \
+    optimizer = Adam(parameters, lr=args.lr) if args.optimizer == 'adam' else \
         torch.optim.SGD(parameters, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
 
     if args.pretrained:

@@ -310,6 +310,14 @@ int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void*
 /* The same for all layers of a network in ONE launch (52 launches per optimizer step otherwise).  table: device
  * array [nlayers][7] of int64: { w (const float*), w16, w16_rot (0 = none), Cout, R*S, Cin, rot_mode }. */
 int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t stream);
+/* torch.optim.Adam.step() (imdb-wiki-dir/train.py:161-162 builds the optimizer, :259-260 steps it) for ALL parameter tensors in one
+ * launch, fused with the bf16 operand preparation of the convolution weights (the job of dir_conv_prep_weights_batched).
+ * table: device [ntensors][12] int64 = (param, grad, exp_avg, exp_avg_sq, numel, w16, w16_rot, Cout, R*S, Cin, rot_mode, 0); rows with
+ * w16 == 0 are plain tensors (BatchNorm affine, the linear layer), the others float32 channels_last conv weights whose bf16
+ * operands are rewritten from the updated value.  step >= 1: the step count after this step (bias corrections on the host in
+ * float64, like torch's non-capturable path).  Arithmetic = torch's single-tensor Adam (no amsgrad / maximize). */
+int dir_adam_step(const void* table, int ntensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  long long step, dir_stream_t stream);
 /* rot_mode 0: as dir_conv_prep_weights.  rot_mode 1 (3x3): w16_rot receives the four parity-class weights of the
  * STRIDE-2 data gradient, packed back to back (class (a, b), a = row parity, b = column parity of the output pixel:
  * (1 + a)(1 + b) taps, [Cin][taps][Cout]; bases at 0, 1, 3, 5 taps x Cin x Cout) — the operand of dir_conv_dgrad_s2. */
