@@ -236,7 +236,7 @@ def measured_peaks(device):
 
 FAMILIES = (("conv_igemm", "conv_igemm"), ("conv3x3_patch", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
             ("bn_", "batchnorm"), ("tail_", "tail"), ("fds_", "fds"), ("loss_", "loss"), ("scale_by_scalar", "loss"),
-            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"))
+            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("adam_step", "optimizer"), ("conv3x3_resident", "conv_igemm"), ("conv_ring", "conv_igemm"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"))
 
 
 def in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch, steps=4):
@@ -758,6 +758,29 @@ def main():
                                  "sum_roofline_ms": {kind: sum(r[8] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
                                  "note": "isolated launches, inputs rotated over > 256 MB of distinct buffers; roofline_us = max(FLOP / 2.5 PF, bytes / 8 TB/s)"}
         result["peaks"] = peaks
+        # ---- what the training step could cost at best with THIS algorithm (training-mode BatchNorm = a grid-wide reduction between
+        # every convolution and its consumer, so no kernel can be fused across it): the sum over its kernels of max(FLOP / MFMA peak,
+        # algorithmic bytes / HBM peak), at the nominal peaks and at the peaks measured on this box
+        def conv_floor(pf, bw):
+            tot = 0.0
+            for cin, cout, k, st, h, cnt, kind, *_ in rows:
+                ho = (h + 2 * (k // 2) - k) // st + 1
+                flop = 2.0 * args.batch * ho * ho * cout * cin * k * k
+                nbytes = (args.batch * h * h * cin + args.batch * ho * ho * cout) * 2
+                tot += cnt * max(flop / pf, nbytes / bw)
+            return tot * 1e3
+        bn_bytes = (5 * 11.11e6 + 2 * 3.11e6) * args.batch * 2
+        stem_bytes = args.batch * (224 * 224 * 3 * 2 * 2 + 112 * 112 * 64 * 2 * 6 + 56 * 56 * 64 * (2 * 3 + 1 * 3))   # image x2, stem map x6, pooled map / indices x3
+        opt_bytes = 23510081 * 4 * 7 + 23454912 * 2 * 2
+        floors = {}
+        for tag, pf, bw in (("nominal", PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_GBS * 1e9), ("measured_on_this_box", peaks["bf16_mfma_TFs"] * 1e12, peaks["stream_copy_GBs"] * 1e9)):
+            parts = {"conv_fwd_dgrad_wgrad_ms": conv_floor(pf, bw), "batchnorm_ms": bn_bytes / bw * 1e3, "stem_ms": stem_bytes / bw * 1e3, "optimizer_ms": opt_bytes / bw * 1e3}
+            floors[tag] = dict(parts, total_ms=sum(parts.values()))
+        step_ms = dt_train / args.steps * 1e3
+        result["roofline_step"] = {"achieved_ms": step_ms, "floor": floors, "frac_of_nominal_floor": floors["nominal"]["total_ms"] / step_ms,
+                                   "frac_of_measured_peak_floor": floors["measured_on_this_box"]["total_ms"] / step_ms,
+                                   "note": "floor = sum over the step's kernels of max(FLOP / bf16 MFMA peak, algorithmic bytes / HBM peak): per conv layer and "
+                                           "direction, BatchNorm family bytes (SURVEY 8d), stem + stem tail, optimizer; batch-statistics BatchNorm forbids fusing across it"}
         log("conv layer probe done")
     if rank == 0 and world == 1 and not args.no_input_pipeline:
         try:

@@ -15,6 +15,8 @@
 
 namespace {
 
+int g_bn_cap_total = 768;
+
 struct BnGeom {
     int ct;             // channel tile handled by one workgroup column (<= 256 for bf16, <= 128 for f32)
     int tpr;            // threads per row inside the tile = ct / VEC
@@ -32,7 +34,7 @@ BnGeom bn_geom(int64_t M, int C) {
     g.rpi = DIR_TPB / g.tpr;
     g.ctiles = C / g.ct;
     int64_t want = (M + (int64_t)g.rpi * 4 - 1) / ((int64_t)g.rpi * 4);   // >= 4 row iterations per workgroup
-    constexpr int cap_total = 768;                      // workgroups = 3 per CU (256..4096 swept in round 1)
+    const int cap_total = g_bn_cap_total;               // workgroups = 3 per CU (256..4096 swept in round 1, 512..2048 again in round 3)
     int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768/ctiles partial rows per channel
     g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     return g;
@@ -860,6 +862,8 @@ extern "C" int dir_bn_bwd_join(const void* g, const void* x, const void* r, void
     return bwd_join_impl<float>(g, x, r, dx, dr, M, C, gamma, save_mean, save_rstd, gamma_r, save_mean_r, save_rstd_r, dgamma, dbeta,
                                 dgamma_r, dbeta_r, workspace, workspace_bytes, dir_s(stream));
 }
+
+extern "C" int dir_bn_set_grid_cap(int cap) { const int prev = g_bn_cap_total; if (cap >= 64) g_bn_cap_total = cap; return prev; }
 
 extern "C" int dir_bn_set_fused_finalize(int mode) { const int prev = g_bn_fused_finalize; g_bn_fused_finalize = mode ? 1 : 0; return prev; }
 

@@ -216,6 +216,8 @@ size_t dir_bn_workspace(int dtype, int64_t M, int C);
  * coefficients INSIDE the apply pass (fold of the partial list + apply: no finalize launch), 0 = fold + finalize + apply (round 2).
  * Returns the previous setting. */
 int dir_bn_set_fused_finalize(int mode);
+/* Measurement knob (tools): workgroups per BatchNorm streaming launch (default 768 = 3 per CU); returns the previous value. */
+int dir_bn_set_grid_cap(int cap);
 int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      double momentum, double eps, int relu, float* save_mean, float* save_rstd,

@@ -1,10 +1,12 @@
 """rocprofv3 kernel_trace.csv of `bench.py` -> per-train-step kernel breakdown of the train-only timed region
-(step boundaries = the 5 fused-Adam launches of each optimizer step)."""
+(step boundaries = the optimizer launch of each step: adam_step_kernel; in older traces the 5 launches of torch's fused Adam)."""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"]]
-steps = [adam[i] for i in range(4, len(adam), 5)]
+steps = [i for i, r in enumerate(rows) if "adam_step_kernel" in r["Kernel_Name"]]
+if not steps:
+    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"]]
+    steps = [adam[i] for i in range(4, len(adam), 5)]
 n = 23
 seg = rows[steps[-(n + 1)] + 1:steps[-1] + 1]
 wall = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
