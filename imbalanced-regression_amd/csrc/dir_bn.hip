@@ -23,7 +23,22 @@ struct BnGeom {
     int rpi;            // rows per iteration = 256 / tpr
     int ctiles;         // C / ct
     int rblocks;        // row blocks (grid.x)
+    int chunk;          // apply passes only: 0 = persistent sweep (grid.x = rblocks, stride rblocks * rpi); > 0 = rows per workgroup,
+                        // consecutive (grid.x = ceil(M / chunk)): short-lived workgroups in address order (dir_bn_set_apply_chunk)
 };
+int g_bn_apply_chunk = 0;
+
+struct BnWalk { int64_t row, stride, end; };
+__device__ __forceinline__ BnWalk bn_walk(const BnGeom& g, int64_t M, int tr) {
+    BnWalk w;
+    if (g.chunk) {
+        const int64_t r0 = (int64_t)blockIdx.x * g.chunk;
+        w.row = r0 + tr; w.stride = g.rpi; w.end = (r0 + g.chunk < M) ? r0 + g.chunk : M;
+    } else {
+        w.row = (int64_t)blockIdx.x * g.rpi + tr; w.stride = (int64_t)gridDim.x * g.rpi; w.end = M;
+    }
+    return w;
+}
 
 template <int VEC>
 BnGeom bn_geom(int64_t M, int C) {
@@ -37,6 +52,15 @@ BnGeom bn_geom(int64_t M, int C) {
     const int cap_total = g_bn_cap_total;               // workgroups = 3 per CU (256..4096 swept in round 1, 512..2048 again in round 3)
     int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768/ctiles partial rows per channel
     g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    g.chunk = 0;
+    return g;
+}
+// geometry of an apply pass: the sweep of bn_geom, or (dir_bn_set_apply_chunk(iters)) `iters` consecutive row groups per workgroup
+inline BnGeom bn_apply_geom(BnGeom g, int64_t M) {
+    if (g_bn_apply_chunk > 0) {
+        g.chunk = g_bn_apply_chunk * g.rpi;
+        g.rblocks = (int)((M + g.chunk - 1) / g.chunk);
+    }
     return g;
 }
 
@@ -319,13 +343,14 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
     for (int j = 0; j < VEC; ++j) {
         a2[j] = RES == 2 ? rcoef[c + j] : 1.0f; b2[j] = RES == 2 ? rcoef[C + c + j] : 0.0f;
     }
-    const int64_t stride = (int64_t)gridDim.x * g.rpi;
+    const BnWalk wk = bn_walk(g, M, tr);
+    const int64_t stride = wk.stride, Mend = wk.end;
     // Mirrored row order (physical row = M-1-row): the statistics pass swept the tensor front to back, so its
     // tail is what L2 / the 256 MiB Infinity Cache still hold — re-read that first. x is read for the last time in the forward
     // pass: non-temporal (A/B -0.15 ms per train step, -0.20 ms per epoch-tail forward); the result is stored normally — the next
     // convolution reads it and finds part of it in cache (non-temporal stores here measured +0.12 ms).
-    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
-    for (; row + stride < M; row += 2 * stride) {
+    int64_t row = wk.row;
+    for (; row + stride < Mend; row += 2 * stride) {
         float v[2][VEC], r[2][VEC];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -347,7 +372,7 @@ bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restric
 
         }
     }
-    for (; row < M; row += stride) {
+    for (; row < Mend; row += stride) {
         float v[VEC], r[VEC];
         Vec<T>::load_nt(x + (M - 1 - row) * C + c, v);
         if (RES) Vec<T>::load(res + (M - 1 - row) * C + c, r);
@@ -489,9 +514,10 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { a[j] = coef[c + j]; p[j] = coef[C + c + j]; q[j] = coef[2 * C + c + j]; }
     }
-    const int64_t stride = (int64_t)gridDim.x * g.rpi;
-    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
-    for (; row + stride < M; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
+    const BnWalk wk = bn_walk(g, M, tr);
+    const int64_t stride = wk.stride, Mend = wk.end;
+    int64_t row = wk.row;
+    for (; row + stride < Mend; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
         float d[2][VEC], v[2][VEC], o[2][VEC];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -514,7 +540,7 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T
             if (DRES) Vec<T>::store(dres + pr * C + c, d[u]);
         }
     }
-    for (; row < M; row += stride) {
+    for (; row < Mend; row += stride) {
         const int64_t pr = M - 1 - row;
         float d[VEC], v[VEC], o[VEC];
         Vec<T>::load_nt(dout + pr * C + c, d);
@@ -589,9 +615,10 @@ bn_bwd_join_apply_kernel(const T* __restrict__ gout, const T* __restrict__ x, co
         a[j] = coef_x[c + j]; p[j] = coef_x[C + c + j]; q[j] = coef_x[2 * C + c + j];
         a2[j] = coef_r[c + j]; p2[j] = coef_r[C + c + j]; q2[j] = coef_r[2 * C + c + j];
     }
-    const int64_t stride = (int64_t)gridDim.x * g.rpi;
-    int64_t row = (int64_t)blockIdx.x * g.rpi + tr;
-    for (; row + stride < M; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
+    const BnWalk wk = bn_walk(g, M, tr);
+    const int64_t stride = wk.stride, Mend = wk.end;
+    int64_t row = wk.row;
+    for (; row + stride < Mend; row += 2 * stride) {          // mirrored rows (see bn_apply_kernel), 2 rows in flight
         float d[2][VEC], v[2][VEC], w[2][VEC];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -612,7 +639,7 @@ bn_bwd_join_apply_kernel(const T* __restrict__ gout, const T* __restrict__ x, co
             Vec<T>::store(dr + pr * C + c, w[u]);
         }
     }
-    for (; row < M; row += stride) {
+    for (; row < Mend; row += stride) {
         const int64_t pr = M - 1 - row;
         float d[VEC], v[VEC], w[VEC];
         Vec<T>::load_nt(gout + pr * C + c, d);
@@ -706,7 +733,7 @@ int apply_impl(const void* x_, const void* res_, const float* rcoef, void* y_, i
                hipStream_t s, uint8_t* bits = nullptr, BnFinF fin = BnFinF{}) {
     constexpr int VEC = Vec<T>::N;
     const T* x = static_cast<const T*>(x_); const T* res = static_cast<const T*>(res_); T* y = static_cast<T*>(y_);
-    BnGeom g = bn_geom<VEC>(M, C);
+    const BnGeom g = bn_apply_geom(bn_geom<VEC>(M, C), M);
     const dim3 grid(g.rblocks, g.ctiles), blk(DIR_TPB);
     if (res && rcoef && relu) hipLaunchKernelGGL((bn_apply_kernel<T, 2, true>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
     else if (res && rcoef) hipLaunchKernelGGL((bn_apply_kernel<T, 2, false>), grid, blk, 0, s, x, res, y, M, C, g, coef, rcoef, bits, fin);
@@ -811,11 +838,13 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
                            save_mean, save_rstd, dgamma, dbeta, w.coef);
         DIR_LAUNCH_CHECK();
     }
-    if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
-    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
-    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, true>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, false>), grid, blk, 0, s, dout, x, out, dx, dres, M, C, g, w.coef, mc, fin);
+    const BnGeom ag = bn_apply_geom(g, M);
+    const dim3 agrid(ag.rblocks, ag.ctiles);
+    if (mask == 1 && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), agrid, blk, 0, s, dout, x, out, dx, dres, M, C, ag, w.coef, mc, fin);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), agrid, blk, 0, s, dout, x, out, dx, dres, M, C, ag, w.coef, mc, fin);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2, false>), agrid, blk, 0, s, dout, x, out, dx, dres, M, C, ag, w.coef, mc, fin);
+    else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, true>), agrid, blk, 0, s, dout, x, out, dx, dres, M, C, ag, w.coef, mc, fin);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0, false>), agrid, blk, 0, s, dout, x, out, dx, dres, M, C, ag, w.coef, mc, fin);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -839,8 +868,9 @@ int bwd_join_impl(const void* g_, const void* x_, const void* r_, void* dx_, voi
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, float>), dim3(dir_cdiv(C, 8)), blk, 0, s, wr.partial, g.rblocks, M, C, gamma_r, mean_r,
                        rstd_r, dgamma_r, dbeta_r, wr.coef);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_join_apply_kernel<T>, grid, blk, 0, s, static_cast<const T*>(g_), static_cast<const T*>(x_),
-                       static_cast<const T*>(r_), static_cast<T*>(dx_), static_cast<T*>(dr_), M, C, g, wx.coef, wr.coef);
+    const BnGeom ag = bn_apply_geom(g, M);
+    hipLaunchKernelGGL(bn_bwd_join_apply_kernel<T>, dim3(ag.rblocks, ag.ctiles), blk, 0, s, static_cast<const T*>(g_), static_cast<const T*>(x_),
+                       static_cast<const T*>(r_), static_cast<T*>(dx_), static_cast<T*>(dr_), M, C, ag, wx.coef, wr.coef);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -864,6 +894,8 @@ extern "C" int dir_bn_bwd_join(const void* g, const void* x, const void* r, void
 }
 
 extern "C" int dir_bn_set_grid_cap(int cap) { const int prev = g_bn_cap_total; if (cap >= 64) g_bn_cap_total = cap; return prev; }
+
+extern "C" int dir_bn_set_apply_chunk(int iters) { const int prev = g_bn_apply_chunk; g_bn_apply_chunk = iters < 0 ? 0 : (iters > 64 ? 64 : iters); return prev; }
 
 extern "C" int dir_bn_set_fused_finalize(int mode) { const int prev = g_bn_fused_finalize; g_bn_fused_finalize = mode ? 1 : 0; return prev; }
 

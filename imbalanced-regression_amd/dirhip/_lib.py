@@ -71,6 +71,7 @@ SIGNATURES = {
     "dir_adam_step": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_longlong, c_void_p]),
     "dir_bn_set_fused_finalize": (c_int, [c_int]),
     "dir_bn_set_grid_cap": (c_int, [c_int]),
+    "dir_bn_set_apply_chunk": (c_int, [c_int]),
     "dir_conv_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_conv_prep_weights_batched": (c_int, [c_void_p, c_int, c_void_p]),
     "dir_conv_prep_weights_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

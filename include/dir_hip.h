@@ -218,6 +218,10 @@ size_t dir_bn_workspace(int dtype, int64_t M, int C);
 int dir_bn_set_fused_finalize(int mode);
 /* Measurement knob (tools): workgroups per BatchNorm streaming launch (default 768 = 3 per CU); returns the previous value. */
 int dir_bn_set_grid_cap(int cap);
+/* Row walk of the element-wise BatchNorm passes (forward apply, backward apply, join apply). 0 = persistent sweep (<= grid-cap
+ * workgroups, each striding over the whole tensor); iters > 0 = one short-lived workgroup per `iters` consecutive 4 KB row groups,
+ * launched in address order. Same arithmetic per element: results are bit-identical. Returns the previous value. */
+int dir_bn_set_apply_chunk(int iters);
 int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      double momentum, double eps, int relu, float* save_mean, float* save_rstd,
