@@ -130,7 +130,7 @@ constexpr int SP_BLOCKS = 1024;                                   // workgroups 
 
 __global__ void __launch_bounds__(DIR_TPB)
 bn_relu_maxpool_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ coef, uint16_t* __restrict__ y,
-                           uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+                           uint8_t* __restrict__ idx, uint16_t* __restrict__ xmax, int N, int H, int W, int C, int Ho, int Wo) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const int cg = C / 8;
@@ -139,9 +139,9 @@ bn_relu_maxpool_fwd_kernel(const uint16_t* __restrict__ x, const float* __restri
         const int g = (int)(i % cg); long long p = i / cg;
         const int wo = (int)(p % Wo); p /= Wo;
         const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
-        float a[8], b[8], best[8]; uint32_t bi[8];
+        float a[8], b[8], best[8]; uint32_t bi[8], bx[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] = coef[g * 8 + j]; b[j] = coef[C + g * 8 + j]; best[j] = -INFINITY; bi[j] = 9; }
+        for (int j = 0; j < 8; ++j) { a[j] = coef[g * 8 + j]; b[j] = coef[C + g * 8 + j]; best[j] = -INFINITY; bi[j] = 9; bx[j] = 0; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int hi = 2 * ho - 1 + r;
@@ -156,8 +156,8 @@ bn_relu_maxpool_fwd_kernel(const uint16_t* __restrict__ x, const float* __restri
                 for (int q = 0; q < 4; ++q) {
                     const float f0 = pl_bf2f(w4[q] & 0xffffu) * a[2 * q] + b[2 * q];
                     const float f1 = pl_bf2f(w4[q] >> 16) * a[2 * q + 1] + b[2 * q + 1];
-                    if (f0 > best[2 * q]) { best[2 * q] = f0; bi[2 * q] = r * 3 + s; }                   // first max wins
-                    if (f1 > best[2 * q + 1]) { best[2 * q + 1] = f1; bi[2 * q + 1] = r * 3 + s; }
+                    if (f0 > best[2 * q]) { best[2 * q] = f0; bi[2 * q] = r * 3 + s; bx[2 * q] = w4[q] & 0xffffu; }   // first max wins
+                    if (f1 > best[2 * q + 1]) { best[2 * q + 1] = f1; bi[2 * q + 1] = r * 3 + s; bx[2 * q + 1] = w4[q] >> 16; }
                 }
             }
         }
@@ -174,13 +174,16 @@ bn_relu_maxpool_fwd_kernel(const uint16_t* __restrict__ x, const float* __restri
         *reinterpret_cast<uint4*>(y + oo) = make_uint4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<uint2*>(idx + oo) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
                                                          bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+        // the BatchNorm INPUT at the argmax (bf16 bits as read): the backward's sum g * x then streams this pooled-size tensor
+        // instead of gathering 2-byte elements out of the 4x larger map
+        if (xmax) *reinterpret_cast<uint4*>(xmax + oo) = make_uint4(bx[0] | (bx[1] << 16), bx[2] | (bx[3] << 16), bx[4] | (bx[5] << 16), bx[6] | (bx[7] << 16));
     }
 }
 
 // partial[block][2][C]: sums of g and g * x over the windows this workgroup visits (fixed order: deterministic)
 __global__ void __launch_bounds__(DIR_TPB)
 bn_relu_maxpool_bwd_partial_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, const uint16_t* __restrict__ x,
-                                   float* __restrict__ partial, int N, int H, int W, int C, int Ho, int Wo) {
+                                   const uint16_t* __restrict__ xmax, float* __restrict__ partial, int N, int H, int W, int C, int Ho, int Wo) {
     extern __shared__ __attribute__((aligned(16))) float sh[];    // [2][DIR_TPB][8]
     const int cg = C / 8;                                         // DIR_TPB % cg == 0: a thread keeps its channel group
     const long long total = (long long)N * Ho * Wo * cg;
@@ -195,6 +198,20 @@ bn_relu_maxpool_bwd_partial_kernel(const uint16_t* __restrict__ dy, const uint8_
         const uint2 iv = *reinterpret_cast<const uint2*>(idx + oo);
         const uint4 gv = *reinterpret_cast<const uint4*>(dy + oo);
         const uint32_t g4[4] = {gv.x, gv.y, gv.z, gv.w};
+        if (xmax) {                                               // x[argmax] was kept by the forward: three streams, no gather
+            const uint4 mv = *reinterpret_cast<const uint4*>(xmax + oo);
+            const uint32_t m4[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t k = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+                if (k < 9u) {
+                    const float gj = pl_bf2f((j & 1) ? (g4[j >> 1] >> 16) : (g4[j >> 1] & 0xffffu));
+                    const float xv = pl_bf2f((j & 1) ? (m4[j >> 1] >> 16) : (m4[j >> 1] & 0xffffu));
+                    s0[j] += gj; s1[j] += gj * xv;
+                }
+            }
+            continue;
+        }
         const size_t xb = (((size_t)n * H + (2 * ho - 1)) * W + (2 * wo - 1)) * C + g * 8;   // window origin (may lie outside: never dereferenced there)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -272,19 +289,108 @@ bn_relu_maxpool_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint8_t*
         *reinterpret_cast<uint4*>(dx + xo) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
 }
+// The same pass with a thread owning the 2 x 2 block of input pixels (2a..2a+1, 2b..2b+1) of its 8 channels: the four pooling
+// windows (a..a+1, b..b+1) that cover the block are loaded once (the per-pixel kernel above loads 2.25 windows per pixel on
+// average, 9 per block) and each pixel adds its windows in the order the per-pixel kernel does — bit-identical results.
+__device__ __forceinline__ void pl_take(float (&acc)[8], const uint2& iv, const uint4& gv, uint32_t me) {
+    const uint32_t g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t k = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+        const uint32_t hbits = (j & 1) ? (g4[j >> 1] >> 16) : (g4[j >> 1] & 0xffffu);
+        if (k == me) acc[j] += pl_bf2f(hbits);
+    }
+}
+__global__ void __launch_bounds__(DIR_TPB)
+bn_relu_maxpool_bwd_apply2x2_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, const uint16_t* __restrict__ x,
+                                    const float* __restrict__ coef, uint16_t* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const int cg = C / 8, Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const long long total = (long long)N * Hb * Wb * cg;
+    const long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % cg); long long p = i / cg;
+    const int b = (int)(p % Wb); p /= Wb;
+    const int a = (int)(p % Hb); const int n = (int)(p / Hb);
+    float ca[8], cp[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ca[j] = coef[g * 8 + j]; cp[j] = coef[C + g * 8 + j]; cq[j] = coef[2 * C + g * 8 + j]; }
+    // windows (a + u, b + v); a < Ho and b < Wo always (Ho = (H - 1) / 2 + 1 >= Hb)
+    uint2 iv[2][2]; uint4 gv[2][2]; bool ok[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            ok[u][v] = (a + u < Ho) && (b + v < Wo);
+            if (ok[u][v]) {
+                const size_t o = (((size_t)n * Ho + a + u) * Wo + b + v) * C + g * 8;
+                iv[u][v] = *reinterpret_cast<const uint2*>(idx + o);
+                gv[u][v] = *reinterpret_cast<const uint4*>(dy + o);
+            }
+        }
+    const bool h1 = 2 * a + 1 < H, w1 = 2 * b + 1 < W;
+    uint4 xv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+            if ((u == 0 || h1) && (v == 0 || w1)) xv[u][v] = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + 2 * a + u) * W + 2 * b + v) * C + g * 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            if (!((u == 0 || h1) && (v == 0 || w1))) continue;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+            // pixel (2a + u, 2b + v): window rows {a + 1 (r = 0), a (r = 2)} for u = 1, {a (r = 1)} for u = 0; columns alike; larger index first
+            if (u == 1 && v == 1) {
+                if (ok[1][1]) pl_take(acc, iv[1][1], gv[1][1], 0u);
+                if (ok[1][0]) pl_take(acc, iv[1][0], gv[1][0], 2u);
+                if (ok[0][1]) pl_take(acc, iv[0][1], gv[0][1], 6u);
+                pl_take(acc, iv[0][0], gv[0][0], 8u);
+            } else if (u == 1) {
+                if (ok[1][0]) pl_take(acc, iv[1][0], gv[1][0], 1u);
+                pl_take(acc, iv[0][0], gv[0][0], 7u);
+            } else if (v == 1) {
+                if (ok[0][1]) pl_take(acc, iv[0][1], gv[0][1], 3u);
+                pl_take(acc, iv[0][0], gv[0][0], 5u);
+            } else {
+                pl_take(acc, iv[0][0], gv[0][0], 4u);
+            }
+            const uint32_t x4[4] = {xv[u][v].x, xv[u][v].y, xv[u][v].z, xv[u][v].w};
+            uint32_t o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = ca[2 * q] * acc[2 * q] + cp[2 * q] * pl_bf2f(x4[q] & 0xffffu) + cq[2 * q];
+                const float v1 = ca[2 * q + 1] * acc[2 * q + 1] + cp[2 * q + 1] * pl_bf2f(x4[q] >> 16) + cq[2 * q + 1];
+                const f32x2_t t = {v0, v1};
+                o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2_t));
+            }
+            *reinterpret_cast<uint4*>(dx + (((size_t)n * H + 2 * a + u) * W + 2 * b + v) * C + g * 8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        }
+}
 }  // namespace
 
-extern "C" int dir_bn_relu_maxpool_fwd(const void* x, const float* coef, void* y, void* argmax, int N, int H, int W, int C,
-                                       dir_stream_t stream) {
+static int g_stem_tail_mode = 3;    // bit 0: backward reduction streams the forward's xmax; bit 1: 2 x 2-block apply pass
+extern "C" int dir_stem_tail_set_mode(int mode) { const int prev = g_stem_tail_mode; g_stem_tail_mode = mode & 3; return prev; }
+
+extern "C" int dir_bn_relu_maxpool_fwd_xmax(const void* x, const float* coef, void* y, void* argmax, void* xmax, int N, int H, int W, int C,
+                                            dir_stream_t stream) {
     DIR_RETURN_IF(!x || !coef || !y || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
     DIR_RETURN_IF(C % 8 != 0, DIR_EUNSUPPORTED);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 8);
     int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const uint16_t*>(x), coef,
-                       static_cast<uint16_t*>(y), static_cast<uint8_t*>(argmax), N, H, W, C, Ho, Wo);
+                       static_cast<uint16_t*>(y), static_cast<uint8_t*>(argmax), static_cast<uint16_t*>(xmax), N, H, W, C, Ho, Wo);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
+}
+extern "C" int dir_bn_relu_maxpool_fwd(const void* x, const float* coef, void* y, void* argmax, int N, int H, int W, int C,
+                                       dir_stream_t stream) {
+    return dir_bn_relu_maxpool_fwd_xmax(x, coef, y, argmax, nullptr, N, H, W, C, stream);
 }
 
 extern "C" size_t dir_bn_relu_maxpool_bwd_workspace(int C) {
@@ -296,7 +402,7 @@ extern "C" size_t dir_bn_relu_maxpool_bwd_workspace(int C) {
 extern "C" int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
                                    const float* save_rstd, float* dgamma, float* dbeta, float* coef, dir_stream_t stream);
 
-extern "C" int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, void* dx, int N, int H, int W, int C,
+extern "C" int dir_bn_relu_maxpool_bwd_xmax(const void* dy, const void* argmax, const void* x, const void* xmax, void* dx, int N, int H, int W, int C,
                                        const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
                                        float* dbeta, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
     DIR_RETURN_IF(!dy || !argmax || !x || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace, DIR_EINVAL);
@@ -308,17 +414,30 @@ extern "C" int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const
     float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + dir_align_up(sizeof(float) * (size_t)SP_BLOCKS * 2 * C, 256));
     hipStream_t s = dir_s(stream);
     hipLaunchKernelGGL(bn_relu_maxpool_bwd_partial_kernel, dim3(SP_BLOCKS), dim3(DIR_TPB), 2 * DIR_TPB * 8 * sizeof(float), s,
-                       static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), partial,
-                       N, H, W, C, Ho, Wo);
+                       static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x),
+                       (g_stem_tail_mode & 1) ? static_cast<const uint16_t*>(xmax) : nullptr, partial, N, H, W, C, Ho, Wo);
     DIR_LAUNCH_CHECK();
     const int rc = dir_bn_bwd_finalize(partial, SP_BLOCKS, (int64_t)N * H * W, C, gamma, save_mean, save_rstd, dgamma, dbeta, coef, stream);
     if (rc != DIR_OK) return rc;
-    const long long total = (long long)N * H * W * (C / 8);
-    int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid), dim3(DIR_TPB), 0, s, static_cast<const uint16_t*>(dy),
-                       static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), coef, static_cast<uint16_t*>(dx), N, H, W, C, Ho, Wo);
+    if (g_stem_tail_mode & 2) {
+        const long long blocks = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply2x2_kernel, dim3((unsigned)((blocks + DIR_TPB - 1) / DIR_TPB)), dim3(DIR_TPB), 0, s,
+                           static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), coef,
+                           static_cast<uint16_t*>(dx), N, H, W, C, Ho, Wo);
+    } else {
+        const long long total = (long long)N * H * W * (C / 8);
+        int grid = (int)((total + DIR_TPB - 1) / DIR_TPB); if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel, dim3(grid), dim3(DIR_TPB), 0, s, static_cast<const uint16_t*>(dy),
+                           static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), coef, static_cast<uint16_t*>(dx), N, H, W, C, Ho, Wo);
+    }
     DIR_LAUNCH_CHECK();
     return DIR_OK;
+}
+
+extern "C" int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, void* dx, int N, int H, int W, int C,
+                                       const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma,
+                                       float* dbeta, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    return dir_bn_relu_maxpool_bwd_xmax(dy, argmax, x, nullptr, dx, N, H, W, C, gamma, save_mean, save_rstd, dgamma, dbeta, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

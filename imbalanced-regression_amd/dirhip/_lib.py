@@ -101,6 +101,10 @@ SIGNATURES = {
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_bn_relu_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_bn_relu_maxpool_fwd_xmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_bn_relu_maxpool_bwd_xmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dir_stem_tail_set_mode": (c_int, [c_int]),
     "dir_bn_relu_maxpool_bwd_workspace": (c_size_t, [c_int]),
     "dir_bn_relu_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -111,6 +111,64 @@ def set_wgrad3_all_taps(enabled):
     return prev
 
 
+# Weight gradients on a SIDE STREAM (set_wgrad_side_stream): nothing in the backward pass reads dW, so the split-K kernels need
+# not sit in the chain  BatchNorm backward -> data gradient -> BatchNorm backward ...; on their own HIP stream they fill the gaps of
+# that chain (its ~5 us fold / finalize launches run on an otherwise idle chip, and every kernel has a tail). The side stream waits
+# for the producer of dY, the operands are marked as in use on it (the caching allocator must not hand their memory out while the
+# kernel runs), and the calling stream waits for the side stream once per backward pass — in an autograd end-of-pass callback, and
+# in front of every gradient-bucket collective (parallel.py) — so `.grad` is ready on the caller's stream when backward() returns.
+_WGRAD_SIDE = {"on": False, "streams": {}, "dirty": set(), "task": None}
+
+
+def set_wgrad_side_stream(enabled):
+    """Returns the previous setting. Turning it off joins whatever is still in flight."""
+    prev = _WGRAD_SIDE["on"]
+    _WGRAD_SIDE["on"] = bool(enabled)
+    if prev and not enabled:
+        wgrad_join()
+    return prev
+
+
+def wgrad_join(device=None):
+    """The current stream of ``device`` (default: every device with weight gradients in flight) waits for the side stream."""
+    dirty = _WGRAD_SIDE["dirty"]
+    for idx in list(dirty):
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        torch.cuda.current_stream(idx).wait_stream(_WGRAD_SIDE["streams"][idx])
+        dirty.discard(idx)
+
+
+def _wgrad_join_callback():
+    _WGRAD_SIDE["task"] = None
+    wgrad_join()
+
+
+def _wgrad_side(device):
+    """The side stream for this call, made to wait for everything queued on the current stream; None = launch in place."""
+    if not _WGRAD_SIDE["on"] or device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _WGRAD_SIDE["streams"].get(idx)
+    if side is None:
+        side = _WGRAD_SIDE["streams"][idx] = torch.cuda.Stream(idx)
+    side.wait_stream(torch.cuda.current_stream(idx))
+    return side
+
+
+def _wgrad_side_done(device, side, *operands):
+    for t in operands:
+        t.record_stream(side)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    _WGRAD_SIDE["dirty"].add(idx)
+    task = torch._C._current_graph_task_id()
+    if task == -1:
+        wgrad_join(device)                                   # called outside a backward pass: plain stream semantics
+    elif _WGRAD_SIDE["task"] != task:
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join_callback)
+        _WGRAD_SIDE["task"] = task
+
+
 def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None):
     """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``. ``sink``: the
     parameter's gradient-bucket factory (``gradsink.lookup``): the kernel then writes into the data-parallel bucket."""
@@ -119,24 +177,35 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None):
         dy = dy.contiguous(memory_format=torch.channels_last)
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
+    cout, cin = dy.shape[1], x.shape[1]
+    dw = gradsink.out_for(sink, (cout, cin, kernel_size, kernel_size), x.device, torch.channels_last)
+    side = _wgrad_side(x.device)
+    if side is None:
+        _wgrad_launch(dy, x, dw, kernel_size, stride, padding)
+    else:
+        with torch.cuda.stream(side):
+            _wgrad_launch(dy, x, dw, kernel_size, stride, padding)
+        _wgrad_side_done(x.device, side, dy, x)
+    return dw
+
+
+def _wgrad_launch(dy, x, dw, kernel_size, stride, padding):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     r = s = kernel_size
-    dw = gradsink.out_for(sink, (cout, cin, r, s), x.device, torch.channels_last)
     if kernel_size == 3 and stride == 1 and padding == 1 and _WGRAD3_ALL_TAPS[0]:
         nbytes = L.lib().dir_conv_wgrad3x3_workspace(n, h, w, cin, cout)
         if nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             L.check(L.lib().dir_conv_wgrad3x3(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
                                               L.stream_ptr(x.device)), "dir_conv_wgrad3x3")
-            return dw
+            return
     nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding)
     if nbytes == 0:
         raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout}")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, L.ptr(ws),
                                    ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
-    return dw
 
 
 class _ConvFn(torch.autograd.Function):

@@ -156,7 +156,10 @@ class DataParallelEngine(nn.Module):
                     self._bucket_of[id(p)] = (bi, pi)
                     if self.world > 1:
                         self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
-                    gradsink.register(p, lambda b=b, pi=pi: b.fresh_view(pi))     # the gradient kernels write into the bucket
+                    # the gradient kernels write into the bucket — unless the parameter still HOLDS a gradient (accumulation over
+                    # several backward passes, zero_grad(set_to_none=False)): the slot is that gradient, so the kernel gets a new tensor
+                    # and autograd accumulates as usual
+                    gradsink.register(p, lambda b=b, pi=pi, p=p: b.fresh_view(pi) if p.grad is None else None)
             self._signature = sig
         for b in self._buckets:
             b.pending = len(b.params)
@@ -179,6 +182,9 @@ class DataParallelEngine(nn.Module):
             self._launch(b)
 
     def _launch(self, b):
+        if b.flat.is_cuda:
+            from . import conv as _conv
+            _conv.wgrad_join(b.flat.device)                  # weight gradients written on the side stream (conv.set_wgrad_side_stream)
         if self.measure_comm and b.flat.is_cuda:
             b.ev0 = torch.cuda.Event(enable_timing=True)
             b.ev0.record()

@@ -113,15 +113,16 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty((n, c, ho, wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
-        L.check(L.lib().dir_bn_relu_maxpool_fwd(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), n, h, w, c, stream),
-                "dir_bn_relu_maxpool_fwd")
-        ctx.save_for_backward(x, gamma, mean, rstd, idx)
+        xmax = torch.empty_like(y)          # x at the argmax, for the backward's sum g * x (pooled size: 1/4 of x)
+        L.check(L.lib().dir_bn_relu_maxpool_fwd_xmax(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), L.ptr(xmax), n, h, w, c, stream),
+                "dir_bn_relu_maxpool_fwd_xmax")
+        ctx.save_for_backward(x, gamma, mean, rstd, idx, xmax)
         ctx.beta_sink = gradsink.lookup(beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd, idx = ctx.saved_tensors
+        x, gamma, mean, rstd, idx, xmax = ctx.saved_tensors
         n, c, h, w = x.shape
         dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
         if dy.dtype != torch.bfloat16:
@@ -131,9 +132,9 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         dgamma = gradsink.out_for(gamma, (c,), dev)
         dbeta = gradsink.out_for(ctx.beta_sink, (c,), dev)
         ws = torch.empty(L.lib().dir_bn_relu_maxpool_bwd_workspace(c), dtype=torch.uint8, device=dev)
-        L.check(L.lib().dir_bn_relu_maxpool_bwd(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
-                                                L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
-                "dir_bn_relu_maxpool_bwd")
+        L.check(L.lib().dir_bn_relu_maxpool_bwd_xmax(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(xmax), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
+                                                     L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
+                "dir_bn_relu_maxpool_bwd_xmax")
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

@@ -459,6 +459,18 @@ size_t dir_bn_relu_maxpool_bwd_workspace(int C);
 int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, void* dx, int N, int H, int W, int C,
                             const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                             void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* The same pair with the BatchNorm input AT THE ARGMAX kept by the forward (xmax [N, Ho, Wo, C] bf16, the bits of x as read): the
+ * backward's reduction (sum g, sum g x) then streams three pooled-size tensors instead of gathering 2-byte elements out of the 4x
+ * larger x. xmax == NULL: as the functions above. Identical results either way (same values, same summation order). */
+int dir_bn_relu_maxpool_fwd_xmax(const void* x, const float* coef, void* y, void* argmax, void* xmax, int N, int H, int W, int C,
+                                 dir_stream_t stream);
+int dir_bn_relu_maxpool_bwd_xmax(const void* dy, const void* argmax, const void* x, const void* xmax, void* dx, int N, int H, int W,
+                                 int C, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                 void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* Measurement / test switch of the stem-tail backward (default 3): bit 0 = the reduction uses xmax when given, bit 1 = the apply pass
+ * runs with one thread per 2 x 2 input block (four windows loaded once) instead of one per pixel. All modes are bit-identical.
+ * Returns the previous mode. */
+int dir_stem_tail_set_mode(int mode);
 /* Second third of dir_bn_bwd on its own: partial [rows][2][C] f32 of (sum g, sum g*x) -> dgamma, dbeta and
  * coef [3][C] = (a, p, q) with dx = a g + p x + q. */
 int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,

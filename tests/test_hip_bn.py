@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from conftest import assert_close
+from dirhip import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -255,3 +256,34 @@ def test_stem_bn_relu_maxpool_matches_unfused():
         assert_close(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running mean")
         assert_close(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), rtol=1e-4, atol_scale=1e-4, msg="running var")
         assert int(bn.num_batches_tracked) == 1
+
+
+def test_stem_tail_backward_modes_bit_identical():
+    """dir_stem_tail_set_mode: the xmax-streaming reduction and the 2 x 2-block apply pass against the gather reduction and the
+    per-pixel apply pass (round 2), even and odd map sizes: dx, dgamma, dbeta equal bit for bit."""
+    from dirhip.pool import bn_relu_maxpool
+    g = torch.Generator(device="cuda").manual_seed(16)
+    for shape in ((8, 64, 112, 112), (3, 64, 9, 7), (2, 64, 10, 15), (2, 32, 8, 8)):
+        x0 = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        c = shape[1]
+        dy = None
+        got = {}
+        for mode in (0, 1, 2, 3):
+            prev = L.lib().dir_stem_tail_set_mode(mode)
+            try:
+                bn = nn.BatchNorm2d(c).cuda()
+                with torch.no_grad():
+                    bn.weight.copy_(torch.linspace(0.5, 1.5, c, device="cuda"))
+                    bn.bias.copy_(torch.linspace(-0.4, 0.4, c, device="cuda"))
+                x = x0.clone().requires_grad_(True)
+                y = bn_relu_maxpool(x, bn, nn.MaxPool2d(3, 2, 1))
+                if dy is None:
+                    dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                y.backward(dy)
+                got[mode] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+            finally:
+                L.lib().dir_stem_tail_set_mode(prev)
+        for mode in (1, 2, 3):
+            for a, b, name in zip(got[mode], got[0], ("y", "dx", "dgamma", "dbeta")):
+                assert torch.equal(a, b), (shape, mode, name)
+
