@@ -745,6 +745,139 @@ conv_igemm_dma_kernel(ConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 CU tile, 16 wavefronts (round 3). The counters say the K loops above are bound by the LDS-staging instructions themselves
+// (one 1 KB `buffer_load ... lds` piece per ~50 clocks and CU at 93 % L2 hits, profiles/r03_conv_l2_counters.txt), so the lever is
+// staged bytes per FLOP: here ONE workgroup of 1024 threads owns a 256 x 256 output tile and its 16 wavefronts — each with the
+// proven 64 x 64 wave tile, four per SIMD as with four independent 128 x 128 workgroups — share one 64 KB K-step stage
+// (A 256 rows + B 256 rows): half the pieces per FLOP (4 per wavefront and K-step instead of 8). Two stages (128 KB), one barrier per
+// K-step. The epilogue is the 128 x 128 one, run by the four 4-wavefront groups on their quadrants (four staging tiles = 152 KB of the
+// LDS the stages no longer need); statistics rows stay one per 128 pixels. Needs Cout % 256 == 0 and M % 256 == 0.
+constexpr int CVB_A = 256 * CV_ROWB, CVB_STAGE = 2 * CVB_A;                        // 32 KB + 32 KB
+constexpr int CVB_EPI = CV_BM * (128 * 2 + 16) + 4 * 2 * 128 * 4;                  // 38 912 B per quadrant
+constexpr int CVB_LDS = (4 * CVB_EPI > 2 * CVB_STAGE) ? 4 * CVB_EPI : 2 * CVB_STAGE;
+template <bool LEAN>
+__global__ void __launch_bounds__(1024)
+conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int MI = 2, NI = 2;
+    int lin;
+    {
+        const int b = blockIdx.x, q = nblocks2 / 8, r = nblocks2 % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int mt2 = lin / ntn2, nt2 = lin - mt2 * ntn2;
+    const int m0 = mt2 * 256, n0 = nt2 * 256;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2, wl = wave & 3, gm = grp >> 1, gn = grp & 1, wm = wl >> 1, wn = wl & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int lr = lane >> 3, lc = lane & 7;
+    int aoff[2];
+    uint32_t amask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+        const int m = m0 + wave * 16 + 8 * i + lr;
+        aoff[i] = 0; amask[i] = 0;
+        if (m < p.M) {
+            if (p.simple) { aoff[i] = (m * p.Cin + chunk * 8) * 2; amask[i] = 1u; continue; }
+            int q1 = (int)((float)m * p.inv_wo), wo = m - q1 * p.Wo;
+            if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+            int n = (int)((float)q1 * p.inv_ho), ho = q1 - n * p.Ho;
+            if (ho < 0) { --n; ho += p.Ho; } else if (ho >= p.Ho) { ++n; ho -= p.Ho; }
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + chunk * 8) * 2;
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2)
+                    if ((unsigned)(hi0 + r) < (unsigned)p.H && (unsigned)(wi0 + s2) < (unsigned)p.W) amask[i] |= 1u << (r * p.S + s2);
+        }
+    }
+    const int K = p.KT * CV_BK;
+    int woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
+        woff[i] = ((n0 + wave * 16 + 8 * i + lr) * K + chunk * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0,
+                                                                           (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), (short)0,
+                                                                           (int)((unsigned)p.Cout * (unsigned)K * 2u), 0x00020000);
+    uint32_t af[MI][4], bf[NI][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = gm * 128 + wm * 64 + mi * 32 + frow;
+            af[mi][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(af[mi][kk]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = gn * 128 + wn * 64 + ni * 32 + frow;
+            bf[ni][kk] = CVB_A + row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(bf[ni][kk]));
+        }
+    }
+    int ld_tap = 0, ld_c = 0, ld_r = 0, ld_s = 0, ld_k = 0;
+#define CVB_ISSUE(stage)                                                                                        \
+    {                                                                                                           \
+        const int koff = ((ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK) * 2;                                      \
+        const uint32_t bit = 1u << ld_tap;                                                                      \
+        const int abase = (stage) * CVB_STAGE + wave * 2048;                                                    \
+        cv_dma16(rs_x, smem + abase, (amask[0] & bit) ? aoff[0] + koff : CV_OOB, 0);                            \
+        cv_dma16(rs_x, smem + abase + 1024, (amask[1] & bit) ? aoff[1] + koff : CV_OOB, 0);                     \
+        const int wso = ld_k * CV_BK * 2;                                                                       \
+        const int bbase = (stage) * CVB_STAGE + CVB_A + wave * 2048;                                            \
+        cv_dma16(rs_w, smem + bbase, woff[0], wso);                                                             \
+        cv_dma16(rs_w, smem + bbase + 1024, woff[1], wso);                                                      \
+        ++ld_k;                                                                                                 \
+        if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
+    }
+#define CVB_MFMA(stage)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll")                                                                                       \
+        for (int kk = 0; kk < 4; ++kk) {                                                                        \
+            bf16x8 a[MI], b[NI];                                                                                \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + (stage) * CVB_STAGE + af[mi][kk]); \
+            _Pragma("unroll")                                                                                   \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + (stage) * CVB_STAGE + bf[ni][kk]); \
+            _Pragma("unroll")                                                                                   \
+            for (int mi = 0; mi < MI; ++mi)                                                                     \
+                _Pragma("unroll")                                                                               \
+                for (int ni = 0; ni < NI; ++ni)                                                                 \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);  \
+        }                                                                                                       \
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+    CVB_ISSUE(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 <= p.KT; kt += 2) {
+        CVB_ISSUE(1);
+        CVB_MFMA(0);
+        __syncthreads();
+        if (kt + 2 < p.KT) CVB_ISSUE(0);
+        CVB_MFMA(1);
+        __syncthreads();
+    }
+    if (kt < p.KT) {
+        CVB_MFMA(0);
+        __syncthreads();
+    }
+#undef CVB_MFMA
+#undef CVB_ISSUE
+    cv_epilogue<128, LEAN, LEAN ? 2 : 4>(p, acc, smem + grp * CVB_EPI, t & 255, m0 + gm * 128, n0 + gn * 128, mt2 * 2 + gm);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 on 56^2, 28^2, 14^2 maps (conv2 of the Bottlenecks and, with rotated weights, its data gradient):
 // the K loops above fetch the A tile once per filter tap — nine shifted copies of the same pixels — and their time is that
 // L2 -> LDS traffic (~12 TB/s chip-wide), not the MFMAs. Here the M tile is a chunk of RB whole image rows (<= 112 pixels of
@@ -1136,6 +1269,28 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
 // A/B switch for tools and tests (process-wide, default 0 — see DESIGN.md for the measurements): 1 = the 128-wide launches that are not patch-staged take the persistent
 // ring kernel (dir_conv_ring.hip), 0 = the one-tile-per-workgroup kernels of this file. Same tiling of M either way (128 rows:
 // the `stats` list does not change). Returns the previous setting.
+// 256 x 256 CU-tile kernel: 0 = off, 1 = on for the launches conv_big_auto() picks (variant 5 of dir_conv_fwd_variant forces it), 2 = wherever
+// the geometry allows (tests). Measured per layer (profiles/r03_conv_big_tiles.txt): it wins from 16 K-steps with >= 150 tiles
+// (1024 -> 256 at 14^2: 46 -> 35 us; 3x3 256 at 14^2: 68 -> 57 us = 1040 TFLOP/s) and loses on short K loops and on the 7^2 layers' 98 tiles.
+static int g_big = 1;
+extern "C" int dir_conv_set_big(int mode) { const int prev = g_big; g_big = (mode < 0 || mode > 2) ? 0 : mode; return prev; }
+static int g_big_min_kt = 16, g_big_min_tiles = 150;
+extern "C" int dir_conv_set_big_thresholds(int min_kt, int min_tiles) { g_big_min_kt = min_kt; g_big_min_tiles = min_tiles; return 0; }   // measurement knob
+static bool conv_big_geometry(long long M, int Cout, int RS) { return Cout % 256 == 0 && M % 256 == 0 && RS <= 9; }
+static bool conv_big_auto(long long M, int Cin, int Cout, int RS) {
+    if (!g_big || !conv_big_geometry(M, Cout, RS)) return false;
+    if (g_big == 2) return true;
+    return RS * (Cin / CV_BK) >= g_big_min_kt && (M / 256) * (Cout / 256) >= g_big_min_tiles;
+}
+// statistics rows of ONE launch of this geometry through the product heuristic (what `stats` / the BatchNorm partial list must hold)
+extern "C" size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
+extern "C" size_t dir_conv_tile_rows_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    if (conv_big_auto((long long)N * Ho * Wo, Cin, Cout, R * S)) return dir_conv_stats_rows(N, Ho, Wo);
+    return dir_conv_tile_rows(N, H, W, R, S, stride, pad);
+}
 static int g_ring = 0;
 static int g_ring_dbg = 0;    // measurement builds only: bit 0 = no fragment reads / MFMA, bit 1 = no LDS-DMA (mode = 1 | dbg << 4)
 extern "C" int dir_conv_set_ring(int mode) { const int prev = g_ring | (g_ring_dbg << 4); g_ring = (mode & 15) ? 1 : 0; g_ring_dbg = mode >> 4; return prev; }
@@ -1163,7 +1318,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 // 1 = register-staged, 2 = LDS-DMA, 3 = patch-staged 3x3; 1 and 2 tile M by 128 rows: stats rows = dir_conv_stats_rows).
 extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                                     int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
-    DIR_RETURN_IF(variant < 0 || variant > 4, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > 5, DIR_EINVAL);
     DIR_RETURN_IF(variant == 3 && !(R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)), DIR_EUNSUPPORTED);
     return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
@@ -1285,7 +1440,9 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int tile_n = wide ? 128 : 64;
     const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
-    const int cpw = (cls || variant == 1 || variant == 2 || variant == 4) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
+    // (takes precedence over the patch-staged 3x3 kernel; dir_conv_tile_rows_ex sizes the caller's statistics buffer with the same rule)
+    const bool big = (variant == 5 && conv_big_geometry(M, Cout, R * S)) || (variant == 0 && conv_big_auto(M, Cin, Cout, R * S) && !(p.addend && p.addend2));
+    const int cpw = (cls || big || variant == 1 || variant == 2 || variant == 4 || variant == 5) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
     if (cpw) {
         // patch-staged 3x3: M tiles = chunks of whole image rows
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
@@ -1325,6 +1482,19 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
         else if (cpw == 28) { if (wide) CP_LAUNCH(28, 128) else CP_LAUNCH(28, 64) }
         else { if (wide) CP_LAUNCH(14, 128) else CP_LAUNCH(14, 64) }
 #undef CP_LAUNCH
+        DIR_LAUNCH_CHECK();
+        return DIR_OK;
+    }
+    DIR_RETURN_IF(variant == 5 && !big, DIR_EUNSUPPORTED);
+    if (big) {
+        // 256 x 256 CU tile on 16 wavefronts (half the LDS-DMA pieces per FLOP)
+        const int ntn2 = Cout / 256, nb2 = (int)(M / 256) * ntn2;
+        static bool once_big = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CVB_LDS),
+                                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CVB_LDS), true);
+        (void)once_big;
+        const bool leanb = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
+        if (leanb) hipLaunchKernelGGL(conv_igemm_big_kernel<true>, dim3(nb2), dim3(1024), CVB_LDS, s, p, ntn2, nb2);
+        else hipLaunchKernelGGL(conv_igemm_big_kernel<false>, dim3(nb2), dim3(1024), CVB_LDS, s, p, ntn2, nb2);
         DIR_LAUNCH_CHECK();
         return DIR_OK;
     }

@@ -66,8 +66,11 @@ SIGNATURES = {
     "dir_bn_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
     "dir_conv_tile_rows": (c_size_t, [c_int] * 7),
+    "dir_conv_tile_rows_ex": (c_size_t, [c_int] * 9),
     "dir_conv_set_patch3x3": (c_int, [c_int]),
     "dir_conv_set_ring": (c_int, [c_int]),
+    "dir_conv_set_big": (c_int, [c_int]),
+    "dir_conv_set_big_thresholds": (c_int, [c_int, c_int]),
     "dir_adam_step": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_longlong, c_void_p]),
     "dir_bn_set_fused_finalize": (c_int, [c_int]),
     "dir_bn_set_grid_cap": (c_int, [c_int]),

@@ -56,7 +56,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     stats = None
     if want_stats:
-        rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, stride, padding)
+        rows = L.lib().dir_conv_tile_rows_ex(n, h, wd, cin, cout, r, s, stride, padding)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     if addend is not None:
         assert addend.shape == y.shape and addend.dtype == torch.bfloat16 and not want_stats
@@ -78,7 +78,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         part, bn_args = None, (None, None, None, None, None)
         if bn_link is not None:
             assert bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
-            rows = L.lib().dir_conv_tile_rows(n, h, wd, r, s, 1, padding)
+            rows = L.lib().dir_conv_tile_rows_ex(n, h, wd, cin, cout, r, s, 1, padding)
             part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
             bn_args = _bn_link_args(bn_link)
         if relu_bits is not None:

@@ -298,6 +298,9 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
  * patch-staged kernel (the input patch of a chunk is staged in LDS once per 64-channel block and all nine taps read it there,
  * instead of nine shifted fetches of the same pixels).  Use this to size `stats` of dir_conv_fwd* / dir_conv_dgrad_bnstats. */
 size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
+/* The same with the channel counts: the 256 x 256 CU-tile kernel (dir_conv_set_big) takes some launches the patch-staged kernel would
+ * otherwise take, with one statistics row per 128 output pixels. This is the function the host side sizes `stats` with. */
+size_t dir_conv_tile_rows_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 /* A/B switch for tools and tests (process-wide, default 1): 0 = the 3x3 / stride-1 layers take the per-tap kernels again (and
  * dir_conv_tile_rows answers accordingly), 1 = patch-staged with one LDS stage (four workgroups per CU), 2 = patch-staged with
  * two stages (two per CU), 3 (round-3 experiment, not faster) = 1, and the 64 -> 64 channel layers on 56^2 maps (conv2 of stage 1 and its
@@ -309,6 +312,12 @@ int dir_conv_set_patch3x3(int mode);
  * persistent ring kernel (csrc/dir_conv_ring.hip: 8 wavefronts per CU with loader / storer roles, LDS-DMA ring across tile
  * boundaries), 0 = the one-tile-per-workgroup kernels.  Same results bit for bit, same `stats` rows.  Returns the previous setting. */
 int dir_conv_set_ring(int mode);
+/* 256 x 256 CU-tile kernel (one 1024-thread workgroup, 16 wavefronts with 64 x 64 wave tiles sharing one 64 KB K-step stage: half the
+ * LDS-DMA pieces per FLOP of the 128 x 128 tiles; same epilogues, results bit-identical). 0 = never, 1 (default) = for launches with >= 16 K-steps
+ * and >= 150 tiles, 2 = whenever the geometry allows (tests). Process-wide; returns the previous mode. */
+int dir_conv_set_big(int mode);
+/* Measurement knob: the two thresholds of mode 1 (defaults 16 K-steps, 150 tiles). */
+int dir_conv_set_big_thresholds(int min_kt, int min_tiles);
 /* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
@@ -394,6 +403,7 @@ int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, 
                         size_t workspace_bytes, dir_stream_t stream);
 
 /* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd, 4 = the persistent ring kernel (DIR_EUNSUPPORTED when the geometry is not taken),
+ * 5 = the 256 x 256 CU-tile kernel on 16 wavefronts (Cout % 256 == 0 and N*Ho*Wo % 256 == 0, else DIR_EUNSUPPORTED),
  * 1 = register-staged loop (global -> VGPR -> ds_write), 2 = LDS-DMA loop (buffer_load ... lds, two stages). */
 int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                          int R, int S, int stride, int pad, int variant, dir_stream_t stream);

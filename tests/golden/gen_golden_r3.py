@@ -172,9 +172,10 @@ def gen_b256_emul32():
     t0 = time.time()
     m32, loss32, pred32, enc32, _ = run(c, torch.float32, True, ckpt=True)
     cols = old["encoding_cols"]
+    _, n32, s32, _ = sampled_grads(m32, c, old["grad_sample_idx"])       # the noise floor of the per-tensor gradient norms / samples
     old.update(emul32_loss=np.array(loss32.item(), dtype=np.float64), emul32_pred=pred32.detach().numpy(),
                emul32_encoding_cols=enc32.detach().numpy()[:, cols], emul32_encoding_rowsum=enc32.detach().double().sum(1).numpy(),
-               emul32_linear_weight_grad=m32.linear.weight.grad.numpy().copy())
+               emul32_linear_weight_grad=m32.linear.weight.grad.numpy().copy(), emul32_grad_norms=n32, emul32_grad_samples=s32.astype(np.float32))
     np.savez_compressed(path, **old)
     print(f"b256 emul32: loss {loss32.item():.9f}  ({time.time() - t0:.0f} s)")
 

@@ -348,6 +348,8 @@ def _emulation_noise_floor(e, cols=False):
         fl["encoding_rel_l2"] = _rel(e["emul32_encoding"].astype(np.float64), e["emul_encoding"].astype(np.float64))
         a, b = e["emul32_l4_bn3_running_var"].astype(np.float64), e["emul_l4_bn3_running_var"].astype(np.float64)
         fl["layer4.2.bn3.running_var_max_rel"] = float(np.max(np.abs(a - b) / (np.abs(b) + 1e-6 * np.abs(b).max())))
+    r = e["emul32_grad_norms"].astype(np.float64) / e["emul_grad_norms"].astype(np.float64)     # per-tensor gradient norms: the floor's own spread
+    fl["grad_norm_ratio_min_max"] = [float(r.min()), float(r.max())]
     return fl
 
 
@@ -358,7 +360,11 @@ def _assert_at_noise_floor(em, fl):
         assert em[k] <= 1.5 * fl[k] + 1e-4, (k, em[k], fl[k])
     assert em["loss_rel_err"] <= 1.5 * fl["loss_rel_err"] + 2e-4, (em["loss_rel_err"], fl["loss_rel_err"])
     assert em["linear_bias_grad_rel"] <= 1e-5, em
-    assert 0.8 <= em["grad_norm_ratio_min_max"][0] and em["grad_norm_ratio_min_max"][1] <= 1.25, em
+    # per-tensor gradient norms (product / float64 emulation): extremes over 161 tensors of a pure-noise quantity — inside the SQUARE of the
+    # band the two emulations span between themselves (B=64: [0.87, 1.19] -> [0.76, 1.42]; B=256: [0.84, 1.29] -> [0.71, 1.67]); the
+    # sharp gradient check is the teacher-forced per-block test
+    lo, hi = fl["grad_norm_ratio_min_max"]
+    assert lo ** 2 <= em["grad_norm_ratio_min_max"][0] and em["grad_norm_ratio_min_max"][1] <= hi ** 2, (em["grad_norm_ratio_min_max"], lo, hi)
 
 
 def test_float32_mode_step_matches_reference_golden_B256(golden):
