@@ -752,12 +752,21 @@ conv_igemm_dma_kernel(ConvP p) {
 // (A 256 rows + B 256 rows): half the pieces per FLOP (4 per wavefront and K-step instead of 8). Two stages (128 KB), one barrier per
 // K-step. The epilogue is the 128 x 128 one, run by the four 4-wavefront groups on their quadrants (four staging tiles = 152 KB of the
 // LDS the stages no longer need); statistics rows stay one per 128 pixels. Needs Cout % 256 == 0 and M % 256 == 0.
-constexpr int CVB_A = 256 * CV_ROWB, CVB_STAGE = 2 * CVB_A;                        // 32 KB + 32 KB
-constexpr int CVB_EPI = CV_BM * (128 * 2 + 16) + 4 * 2 * 128 * 4;                  // 38 912 B per quadrant
-constexpr int CVB_LDS = (4 * CVB_EPI > 2 * CVB_STAGE) ? 4 * CVB_EPI : 2 * CVB_STAGE;
-template <bool LEAN>
-__global__ void __launch_bounds__(1024)
+// The template: TM x TN tile (multiples of 128) on (TM / 64) x (TN / 64) wavefronts, NST LDS stages. <256, 256, 2> is the form described
+// above; <256, 128, 1> (8 wavefronts, one 48 KB stage, two workgroups per CU = the same 16 wavefronts per CU) is the short-K variant:
+// 6 instead of 8 pieces per wavefront and K-step.
+constexpr int CVB_EPI = CV_BM * (128 * 2 + 16) + 4 * 2 * 128 * 4;                  // 38 912 B per 128 x 128 quadrant
+template <int TM, int TN, int NST> struct CvbGeom {
+    static constexpr int NW = (TM / 64) * (TN / 64), THREADS = 64 * NW, NQ = (TM / 128) * (TN / 128), QN = TN / 128;
+    static constexpr int A_BYTES = TM * CV_ROWB, STAGE = (TM + TN) * CV_ROWB;
+    static constexpr int APW = TM / 8 / NW, BPW = TN / 8 / NW;                     // 1 KB pieces per wavefront and K-step (A, B)
+    static constexpr int LDS = (NQ * CVB_EPI > NST * STAGE) ? NQ * CVB_EPI : NST * STAGE;
+    static_assert(APW >= 1 && BPW >= 1 && (TM / NW) % 16 == 0 && (TN / NW) % 16 == 0, "a wavefront loads whole 16-row groups (the swizzle phase)");
+};
+template <int TM, int TN, int NST, bool LEAN>
+__global__ void __launch_bounds__((CvbGeom<TM, TN, NST>::THREADS)) __attribute__((amdgpu_waves_per_eu(4)))
 conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
+    using G = CvbGeom<TM, TN, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MI = 2, NI = 2;
     int lin;
@@ -766,18 +775,18 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
     const int mt2 = lin / ntn2, nt2 = lin - mt2 * ntn2;
-    const int m0 = mt2 * 256, n0 = nt2 * 256;
+    const int m0 = mt2 * TM, n0 = nt2 * TN;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = wave >> 2, wl = wave & 3, gm = grp >> 1, gn = grp & 1, wm = wl >> 1, wn = wl & 1;
+    const int grp = wave >> 2, wl = wave & 3, gm = grp / G::QN, gn = grp - gm * G::QN, wm = wl >> 1, wn = wl & 1;
     const int frow = lane & 31, fhalf = lane >> 5;
     const int lr = lane >> 3, lc = lane & 7;
-    int aoff[2];
-    uint32_t amask[2];
+    int aoff[G::APW];
+    uint32_t amask[G::APW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < G::APW; ++i) {
         const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
-        const int m = m0 + wave * 16 + 8 * i + lr;
+        const int m = m0 + wave * (TM / G::NW) + 8 * i + lr;
         aoff[i] = 0; amask[i] = 0;
         if (m < p.M) {
             if (p.simple) { aoff[i] = (m * p.Cin + chunk * 8) * 2; amask[i] = 1u; continue; }
@@ -793,11 +802,11 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
         }
     }
     const int K = p.KT * CV_BK;
-    int woff[2];
+    int woff[G::BPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < G::BPW; ++i) {
         const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
-        woff[i] = ((n0 + wave * 16 + 8 * i + lr) * K + chunk * 8) * 2;
+        woff[i] = ((n0 + wave * (TN / G::NW) + 8 * i + lr) * K + chunk * 8) * 2;
     }
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0,
                                                                            (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.Cin * 2u), 0x00020000);
@@ -815,7 +824,7 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int row = gn * 128 + wn * 64 + ni * 32 + frow;
-            bf[ni][kk] = CVB_A + row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
+            bf[ni][kk] = G::A_BYTES + row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
             asm volatile("" : "+v"(bf[ni][kk]));
         }
     }
@@ -824,13 +833,13 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
     {                                                                                                           \
         const int koff = ((ld_r * p.W + ld_s) * p.Cin + ld_c * CV_BK) * 2;                                      \
         const uint32_t bit = 1u << ld_tap;                                                                      \
-        const int abase = (stage) * CVB_STAGE + wave * 2048;                                                    \
-        cv_dma16(rs_x, smem + abase, (amask[0] & bit) ? aoff[0] + koff : CV_OOB, 0);                            \
-        cv_dma16(rs_x, smem + abase + 1024, (amask[1] & bit) ? aoff[1] + koff : CV_OOB, 0);                     \
+        const int abase = (stage) * G::STAGE + wave * (G::APW * 1024);                                          \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < G::APW; ++i) cv_dma16(rs_x, smem + abase + i * 1024, (amask[i] & bit) ? aoff[i] + koff : CV_OOB, 0); \
         const int wso = ld_k * CV_BK * 2;                                                                       \
-        const int bbase = (stage) * CVB_STAGE + CVB_A + wave * 2048;                                            \
-        cv_dma16(rs_w, smem + bbase, woff[0], wso);                                                             \
-        cv_dma16(rs_w, smem + bbase + 1024, woff[1], wso);                                                      \
+        const int bbase = (stage) * G::STAGE + G::A_BYTES + wave * (G::BPW * 1024);                             \
+        _Pragma("unroll")                                                                                       \
+        for (int i = 0; i < G::BPW; ++i) cv_dma16(rs_w, smem + bbase + i * 1024, woff[i], wso);                 \
         ++ld_k;                                                                                                 \
         if (++ld_c == p.cpk) { ld_c = 0; ++ld_tap; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }                   \
     }
@@ -840,9 +849,9 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
         for (int kk = 0; kk < 4; ++kk) {                                                                        \
             bf16x8 a[MI], b[NI];                                                                                \
             _Pragma("unroll")                                                                                   \
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + (stage) * CVB_STAGE + af[mi][kk]); \
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + (stage) * G::STAGE + af[mi][kk]); \
             _Pragma("unroll")                                                                                   \
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + (stage) * CVB_STAGE + bf[ni][kk]); \
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + (stage) * G::STAGE + bf[ni][kk]); \
             _Pragma("unroll")                                                                                   \
             for (int mi = 0; mi < MI; ++mi)                                                                     \
                 _Pragma("unroll")                                                                               \
@@ -857,24 +866,33 @@ conv_igemm_big_kernel(ConvP p, int ntn2, int nblocks2) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-    CVB_ISSUE(0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 2 <= p.KT; kt += 2) {
-        CVB_ISSUE(1);
-        CVB_MFMA(0);
+    if (NST == 1) {
+        for (int kt = 0; kt < p.KT; ++kt) {
+            CVB_ISSUE(0);
+            __syncthreads();
+            CVB_MFMA(0);
+            __syncthreads();
+        }
+    } else {
+        CVB_ISSUE(0);
         __syncthreads();
-        if (kt + 2 < p.KT) CVB_ISSUE(0);
-        CVB_MFMA(1);
-        __syncthreads();
-    }
-    if (kt < p.KT) {
-        CVB_MFMA(0);
-        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 <= p.KT; kt += 2) {
+            CVB_ISSUE(1);
+            CVB_MFMA(0);
+            __syncthreads();
+            if (kt + 2 < p.KT) CVB_ISSUE(0);
+            CVB_MFMA(1);
+            __syncthreads();
+        }
+        if (kt < p.KT) {
+            CVB_MFMA(0);
+            __syncthreads();
+        }
     }
 #undef CVB_MFMA
 #undef CVB_ISSUE
-    cv_epilogue<128, LEAN, LEAN ? 2 : 4>(p, acc, smem + grp * CVB_EPI, t & 255, m0 + gm * 128, n0 + gn * 128, mt2 * 2 + gm);
+    cv_epilogue<128, LEAN, LEAN ? 2 : 4>(p, acc, smem + grp * CVB_EPI, t & 255, m0 + gm * 128, n0 + gn * 128, mt2 * (TM / 128) + gm);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1273,7 +1291,8 @@ static int conv_launch(const void* x, const void* w, const void* addend, const v
 // the geometry allows (tests). Measured per layer (profiles/r03_conv_big_tiles.txt): it wins from 16 K-steps with >= 150 tiles
 // (1024 -> 256 at 14^2: 46 -> 35 us; 3x3 256 at 14^2: 68 -> 57 us = 1040 TFLOP/s) and loses on short K loops and on the 7^2 layers' 98 tiles.
 static int g_big = 1;
-extern "C" int dir_conv_set_big(int mode) { const int prev = g_big; g_big = (mode < 0 || mode > 2) ? 0 : mode; return prev; }
+static int g_tall = 0;       // 256 x 128 single-stage form for K loops <= 18 steps (measurement switch: dir_conv_set_big(mode | 4))
+extern "C" int dir_conv_set_big(int mode) { const int prev = g_big | (g_tall << 2); g_tall = (mode >> 2) & 1; mode &= 3; g_big = mode > 2 ? 0 : mode; return prev; }
 static int g_big_min_kt = 16, g_big_min_tiles = 150;
 extern "C" int dir_conv_set_big_thresholds(int min_kt, int min_tiles) { g_big_min_kt = min_kt; g_big_min_tiles = min_tiles; return 0; }   // measurement knob
 static bool conv_big_geometry(long long M, int Cout, int RS) { return Cout % 256 == 0 && M % 256 == 0 && RS <= 9; }
@@ -1318,7 +1337,7 @@ extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* adde
 // 1 = register-staged, 2 = LDS-DMA, 3 = patch-staged 3x3; 1 and 2 tile M by 128 rows: stats rows = dir_conv_stats_rows).
 extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                                     int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
-    DIR_RETURN_IF(variant < 0 || variant > 5, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > 6, DIR_EINVAL);
     DIR_RETURN_IF(variant == 3 && !(R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)), DIR_EUNSUPPORTED);
     return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
@@ -1441,8 +1460,11 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     const int tile_n = wide ? 128 : 64;
     const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
     // (takes precedence over the patch-staged 3x3 kernel; dir_conv_tile_rows_ex sizes the caller's statistics buffer with the same rule)
-    const bool big = (variant == 5 && conv_big_geometry(M, Cout, R * S)) || (variant == 0 && conv_big_auto(M, Cin, Cout, R * S) && !(p.addend && p.addend2));
-    const int cpw = (cls || big || variant == 1 || variant == 2 || variant == 4 || variant == 5) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
+    // variant 6 / g_tall: the 256 x 128 single-stage form (8 wavefronts, two workgroups per CU) for short K loops
+    const bool tall = (variant == 6 && M % 256 == 0 && Cout % 128 == 0 && R * S <= 9) ||
+                      (variant == 0 && g_tall && M % 256 == 0 && Cout % 128 == 0 && R * S <= 9 && p.KT <= 18 && !(p.addend && p.addend2) && !cp_width(H, W, R, S, stride, pad));
+    const bool big = tall || (variant == 5 && conv_big_geometry(M, Cout, R * S)) || (variant == 0 && conv_big_auto(M, Cin, Cout, R * S) && !(p.addend && p.addend2));
+    const int cpw = (cls || big || variant == 1 || variant == 2 || variant == 4 || variant == 5 || variant == 6) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
     if (cpw) {
         // patch-staged 3x3: M tiles = chunks of whole image rows
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
@@ -1485,16 +1507,22 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
         DIR_LAUNCH_CHECK();
         return DIR_OK;
     }
-    DIR_RETURN_IF(variant == 5 && !big, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF((variant == 5 || variant == 6) && !big, DIR_EUNSUPPORTED);
     if (big) {
         // 256 x 256 CU tile on 16 wavefronts (half the LDS-DMA pieces per FLOP)
-        const int ntn2 = Cout / 256, nb2 = (int)(M / 256) * ntn2;
-        static bool once_big = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CVB_LDS),
-                                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CVB_LDS), true);
-        (void)once_big;
         const bool leanb = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
-        if (leanb) hipLaunchKernelGGL(conv_igemm_big_kernel<true>, dim3(nb2), dim3(1024), CVB_LDS, s, p, ntn2, nb2);
-        else hipLaunchKernelGGL(conv_igemm_big_kernel<false>, dim3(nb2), dim3(1024), CVB_LDS, s, p, ntn2, nb2);
+#define CVB_GO(TM_, TN_, NST_)                                                                                                            \
+        {                                                                                                                                 \
+            using G = CvbGeom<TM_, TN_, NST_>;                                                                                            \
+            static bool once_big = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<TM_, TN_, NST_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), \
+                                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<TM_, TN_, NST_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), true); \
+            (void)once_big;                                                                                                               \
+            const int ntn2 = Cout / TN_, nb2 = (int)(M / TM_) * ntn2;                                                                     \
+            if (leanb) hipLaunchKernelGGL((conv_igemm_big_kernel<TM_, TN_, NST_, true>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2); \
+            else hipLaunchKernelGGL((conv_igemm_big_kernel<TM_, TN_, NST_, false>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2); \
+        }
+        if (tall) CVB_GO(256, 128, 1) else CVB_GO(256, 256, 2)
+#undef CVB_GO
         DIR_LAUNCH_CHECK();
         return DIR_OK;
     }

@@ -314,7 +314,7 @@ int dir_conv_set_patch3x3(int mode);
 int dir_conv_set_ring(int mode);
 /* 256 x 256 CU-tile kernel (one 1024-thread workgroup, 16 wavefronts with 64 x 64 wave tiles sharing one 64 KB K-step stage: half the
  * LDS-DMA pieces per FLOP of the 128 x 128 tiles; same epilogues, results bit-identical). 0 = never, 1 (default) = for launches with >= 16 K-steps
- * and >= 150 tiles, 2 = whenever the geometry allows (tests). Process-wide; returns the previous mode. */
+ * and >= 150 tiles, 2 = whenever the geometry allows (tests); + 4 = K loops of <= 18 steps take the 256 x 128 single-stage form (measurement). Process-wide; returns the previous mode. */
 int dir_conv_set_big(int mode);
 /* Measurement knob: the two thresholds of mode 1 (defaults 16 K-steps, 150 tiles). */
 int dir_conv_set_big_thresholds(int min_kt, int min_tiles);
@@ -404,6 +404,7 @@ int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, 
 
 /* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd, 4 = the persistent ring kernel (DIR_EUNSUPPORTED when the geometry is not taken),
  * 5 = the 256 x 256 CU-tile kernel on 16 wavefronts (Cout % 256 == 0 and N*Ho*Wo % 256 == 0, else DIR_EUNSUPPORTED),
+ * 6 = its 256 x 128 single-stage form on 8 wavefronts (two workgroups per CU; measured slower everywhere, kept for the probes),
  * 1 = register-staged loop (global -> VGPR -> ds_write), 2 = LDS-DMA loop (buffer_load ... lds, two stages). */
 int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
                          int R, int S, int stride, int pad, int variant, dir_stream_t stream);

@@ -13,9 +13,12 @@ import check_ring as R  # noqa: E402
 from check_ring import L  # noqa: E402
 
 
+MODES = (0, 4) if (len(sys.argv) > 1 and sys.argv[1] == "tall") else (0, 2)      # tall: the 256 x 128 single-stage form (K loops <= 18 steps)
+
+
 def both(fn):
     out = []
-    for mode in (0, 2):
+    for mode in MODES:
         prev = L.lib().dir_conv_set_big(mode)
         try:
             out.append(fn())
