@@ -1,7 +1,7 @@
 """Where does the 1x1 weight-gradient kernel (conv_wgrad_kernel<128, 128, SIMPLE, PF = 2>) spend its time?  Builds of a patched COPY of
 csrc/dir_conv_wgrad.hip with one phase removed (as tools/ablate_conv.py; results are wrong on purpose):
     full / nomfma (fragment reads kept) / nofrag (no fragment reads, no MFMA) / noload (no global loads) / nostore (no transposing LDS
-    writes) / loadonly (global loads + barriers only)
+    writes) / loadonly (global loads + barriers only) / qpart, nopart (a quarter / none of the partial-tile stores of the epilogue)
     python tools/ablate_wgrad.py build ;  python tools/ablate_wgrad.py run [B]     (GPU box)"""
 import os
 import subprocess
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "imbalanced-regression_amd", "csrc")
 OUTD = os.path.join(ROOT, "imbalanced-regression_amd", "dirhip")
 BUILD = os.path.join(ROOT, "build_ablate")
-NAMES = ["full", "nomfma", "nofrag", "noload", "nostore", "loadonly"]
+NAMES = ["full", "nomfma", "nofrag", "noload", "nostore", "loadonly", "qpart", "nopart"]
 MFMA = "acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);   \\"
 LOADA = "S##a0 = WG_BL(rs_dy,"
 
@@ -31,6 +31,12 @@ def patched(src, name):
         src = src.replace("        if (doA) wg_transpose_store(As + (buf) * A_BYTES, aw, S##a0, S##a1, S##a2, S##a3);                        \\",
                           "        if ((S##a0.x ^ S##a1.y ^ S##a2.z ^ S##a3.w ^ S##b0.x ^ S##b1.y ^ S##b2.z ^ S##b3.w) == 0x12345u) As[t] = 1;         \\")
         src = src.replace("        if (doB) wg_transpose_store(Bs + (buf) * B_BYTES, bw, S##b0, S##b1, S##b2, S##b3);                        \\", "        \\")
+    if name in ("qpart", "nopart"):
+        # the partial-tile stores of the epilogue (4-byte stores, 64 per lane): a quarter of them / none
+        old = "                ob[toff] = acc[mi][ni][e];"
+        assert src.count(old) == 1
+        src = src.replace(old, "                if ((e & 3) == 0) ob[toff] = acc[mi][ni][e];" if name == "qpart" else
+                          "                if (acc[mi][ni][e] == 12345.678f) ob[toff] = acc[mi][ni][e];")
     return src
 
 
