@@ -39,15 +39,26 @@ class BwdLink:
     ``needs_relu_claim``: the BatchNorm output went through ``relu(. + residual)``, so the sums are only right when the
     consumer also applies that ReLU's backward (``defer_relu_grad`` claimed).
     CONTRACT (checked where it is cheap): the BatchNorm output has exactly ONE consumer and that consumer's backward runs first; it
-    records the storage address of the gradient tensor it wrote (``dout_ptr``) next to ``partial``, and the BatchNorm backward takes
-    the sums only if the ``dout`` autograd hands it IS that tensor — if anything else contributed to the gradient (an auxiliary
-    head, a hook, another wiring of the block) autograd has summed into a new tensor and the reduction pass runs as usual."""
-    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "recompute_mask", "needs_relu_claim", "partial", "dout_ptr")
+    records the gradient tensor it wrote (``note_dout``: the tensor itself, its storage address and its version counter) next to
+    ``partial``, and the BatchNorm backward takes the sums only if the ``dout`` autograd hands it IS that tensor, unmodified — if
+    anything else contributed to the gradient (an auxiliary head, a hook, another wiring of the block) autograd has summed into a
+    new tensor and the reduction pass runs as usual. Holding the tensor here is what makes that reliable in either arrival order:
+    autograd's input buffer accumulates IN PLACE into a first-arrived gradient nobody else references (same address, so an address
+    test alone would pass); a second reference forces the out-of-place sum, and the version counter catches any other in-place edit."""
+    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "recompute_mask", "needs_relu_claim", "partial", "dout_ptr", "dout_ref", "dout_version")
 
     def __init__(self):
         self.x = self.gamma = self.beta = self.mean = self.rstd = self.partial = None
         self.recompute_mask = self.needs_relu_claim = False
-        self.dout_ptr = None
+        self.dout_ptr = self.dout_ref = self.dout_version = None
+
+    def note_dout(self, t):
+        self.dout_ref, self.dout_ptr, self.dout_version = t, t.data_ptr(), t._version
+
+    def is_dout(self, t):
+        ok = self.dout_ref is not None and self.dout_ptr == t.data_ptr() and self.dout_version == t._version and t.shape == self.dout_ref.shape
+        self.dout_ref = None
+        return ok
 
 
 class _BNActFn(torch.autograd.Function):
@@ -129,9 +140,11 @@ class _BNActFn(torch.autograd.Function):
         dbeta = gradsink.out_for(beta, (c,), x.device)
         ws = _ws(code, m, c, x.device)
         link = getattr(ctx, "link", None)
-        part = None if link is None else link.partial
-        if part is not None and link.dout_ptr != dout.data_ptr():
-            part, link.partial = None, None                  # the sums are of another tensor than the gradient we were handed
+        part = None
+        if link is not None:
+            part, same = link.partial, link.is_dout(dout)    # (is_dout also drops the link's reference to the gradient)
+            if part is not None and not same:
+                part, link.partial = None, None                  # the sums are of another tensor than the gradient we were handed
         if part is not None and dres is None and y is None:
             # the consumer's data-gradient kernel already summed dout and dout * x per channel (BwdLink): finalize + apply only
             link.partial = None

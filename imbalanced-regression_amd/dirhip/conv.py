@@ -88,7 +88,7 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
                 "dir_conv_dgrad_ex")
         if bn_link is not None:
             bn_link.partial = part
-            bn_link.dout_ptr = y.data_ptr()
+            bn_link.note_dout(y)
         return y
     if addend_s2 is not None:
         L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
@@ -273,7 +273,7 @@ class _ConvFn(torch.autograd.Function):
                                                           *_bn_link_args(link), L.ptr(part), L.stream_ptr(x.device)),
                         "dir_conv_dgrad_s2_bnstats")
                 link.partial = part
-                link.dout_ptr = dx.data_ptr()
+                link.note_dout(dx)
             else:
                 L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
                                                   L.stream_ptr(x.device)), "dir_conv_dgrad_s2")

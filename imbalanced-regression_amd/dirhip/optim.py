@@ -32,7 +32,33 @@ class Adam(torch.optim.Adam):
                 return False
             if p.stride() != g.stride() or not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
                 return False
+            st = self.state.get(p)
+            if st:                                                          # the kernel walks param, grad and both moments with ONE linear index
+                for k in ("exp_avg", "exp_avg_sq"):
+                    t = st.get(k)
+                    if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.device == dev and t.shape == p.shape):
+                        return False
+                    if t.stride() != p.stride():
+                        # e.g. a reference (NCHW-contiguous) optimizer checkpoint loaded next to channels_last parameters:
+                        # load_state_dict keeps the loaded strides. Re-lay the moment out once, same values, the parameter's strides
+                        st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
         return True
+
+    def _drop_tables(self):
+        self._tables = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._drop_tables()                                                 # the cached table holds addresses of the replaced state tensors
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_tables"):
+            self._drop_tables()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -45,7 +71,8 @@ class Adam(torch.optim.Adam):
             if not params:
                 continue
             if not self._ours(group, params):
-                return super().step(None) if loss is None else loss        # torch's own step for every group (never a mix)
+                super().step(None)                                          # torch's own step for every group (never a mix)
+                return loss
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
@@ -64,7 +91,7 @@ class Adam(torch.optim.Adam):
                 elif s != step:
                     raise L.DirHipError("dirhip.optim.Adam: parameters of one group with different step counts")
             dev = params[0].device
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in params)
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
                 prepared = _conv.prepared_operands(dev)                     # master-weight address -> the layer's bf16 operand buffers

@@ -101,7 +101,12 @@ class DataParallelEngine(nn.Module):
         self.measure_comm = False                       # bench.py: HIP events around the tail of the backward pass
         # mean over ranks: RCCL reduces with AVG itself; other backends (gloo: tests) get gradients pre-scaled by 1 / world at the
         # network's output (one [B, 1] kernel; exact for power-of-two world sizes) — never a pass over the 94 MB of buckets
+        # — EXCEPT when a backward pass starts with gradients already held (accumulation over several backward passes without
+        # zero_grad): the bucket then holds the previous, already averaged gradient, and SUM over ranks of (mean_1 + local_2 / world)
+        # would count mean_1 `world` times. That pass sums the unscaled gradients and scales the buckets afterwards instead
+        # (SUM(mean_1 + local_2) / world = mean_1 + mean_2, what AVG gives on RCCL); `bucket_scale_kernels` counts those passes.
         self._native_avg = bool(self.world > 1 and dist.get_backend(process_group) == "nccl")
+        self._accumulating = False
         if channels_last:
             self.module.to(memory_format=torch.channels_last)
         if self.world > 1 and broadcast_from_rank0:
@@ -125,7 +130,7 @@ class DataParallelEngine(nn.Module):
                 out = self.module(inputs, *args, **kwargs)
         else:
             out = self.module(inputs, *args, **kwargs)
-        if self.world > 1 and not self._native_avg and self.training and torch.is_grad_enabled():
+        if self.world > 1 and not self._native_avg and self.training and torch.is_grad_enabled() and not self._accumulating:
             inv = 1.0 / self.world
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(t, torch.Tensor) and t.requires_grad:
@@ -165,6 +170,7 @@ class DataParallelEngine(nn.Module):
             b.pending = len(b.params)
             b.work = None
         self._callback_queued = False
+        self._accumulating = bool(self.world > 1 and any(p.grad is not None for p in params))
 
     def _on_grad_ready(self, p):
         if not self._callback_queued:
@@ -209,6 +215,9 @@ class DataParallelEngine(nn.Module):
             ev_a.record()                                    # the compute stream has everything of the backward pass queued
         for b in self._buckets:
             b.work.wait()                                    # (the compute stream waits for the collective; the host does not)
+            if self._accumulating and not self._native_avg:
+                b.flat.mul_(1.0 / self.world)
+                self.stats["bucket_scale_kernels"] += 1
         if ev_b is not None:
             ev_b.record()
             self._pending_events = (ev_a, ev_b)

@@ -111,3 +111,48 @@ def test_training_step_launches_no_library_optimizer_kernel():
     key0 = opt._tables[0][0]
     train_step(eng, opt, x, y, w, 0, weighted_l1_loss, fds=False)
     assert opt._tables[0][0] == key0
+
+
+def test_adam_loads_reference_layout_state_into_channels_last_model():
+    """a reference optimizer checkpoint holds NCHW-contiguous moments; load_state_dict keeps those strides next to
+    channels_last parameters. The one-linear-index kernel must not see them as they are: the moments are re-laid out once
+    (same values) and the cached address table is rebuilt. Checked against torch.optim.Adam given the same state."""
+    from dirhip.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (64,), (8, 16)]
+    def make():
+        ps = []
+        for i, s in enumerate(shapes):
+            t = torch.randn(s, generator=torch.Generator().manual_seed(10 + i)).cuda()
+            if t.dim() == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    ours_p, ref_p = make(), make()
+    ours, ref = Adam(ours_p, lr=1e-2), torch.optim.Adam(ref_p, lr=1e-2, foreach=False, fused=False)
+    def grads(seed):
+        for i, (a, b) in enumerate(zip(ours_p, ref_p)):
+            g = torch.randn(a.shape, generator=torch.Generator().manual_seed(seed + i)).cuda()
+            if g.dim() == 4:
+                g = g.contiguous(memory_format=torch.channels_last)
+            a.grad, b.grad = g.clone(memory_format=torch.preserve_format), g.clone(memory_format=torch.preserve_format)
+    grads(100)
+    ours.step(); ref.step()
+    # a reference-layout checkpoint: every moment NCHW-contiguous
+    sd = ref.state_dict()
+    for st in sd["state"].values():
+        for k in ("exp_avg", "exp_avg_sq"):
+            st[k] = st[k].contiguous().clone()
+    tables_before = dict(ours._tables)
+    ours.load_state_dict(copy.deepcopy(sd)); ref.load_state_dict(copy.deepcopy(sd))
+    assert ours._tables == {} and tables_before                  # stale addresses dropped
+    assert ours.state[ours_p[0]]["exp_avg"].stride() != ours_p[0].stride()          # torch kept the loaded strides
+    for seed in (200, 300):
+        grads(seed)
+        ours.step(); ref.step()
+    torch.cuda.synchronize()
+    for a, b in zip(ours_p, ref_p):
+        assert ours.state[a]["exp_avg"].stride() == a.stride()
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+        assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-6, atol=1e-12)
+        assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-6, atol=1e-20)

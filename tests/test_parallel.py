@@ -77,3 +77,37 @@ def test_shard_indices_cover_and_pad():
     assert set(allidx.tolist()) == set(range(n))
     assert torch.equal(shard_indices(n, 0, 1), torch.arange(n))
     assert not torch.equal(shard_indices(n, 0, world, epoch_seed=5), shard_indices(n, 0, world, epoch_seed=6))
+
+
+def _accum_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dirhip.parallel import DataParallelEngine
+    eng = DataParallelEngine(_net(), bucket_mb=0.001)
+    eng.train()
+    d = np.load(os.path.join(tmp, "data.npz"))
+    x, y = torch.tensor(d["x"]), torch.tensor(d["y"])
+    for it in range(2):                                     # two backward passes, NO zero_grad in between
+        ((eng(x[it, rank::world]) - y[it, rank::world]) ** 2).mean().backward()
+    assert eng.stats["bucket_scale_kernels"] == len(eng._buckets)          # only the second (accumulating) pass scales its buckets
+    torch.save({k: p.grad.clone() for k, p in eng.module.named_parameters()}, os.path.join(tmp, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_world_size_2_gloo(tmp_path):
+    """on the non-RCCL path an accumulating backward pass must not count the already averaged first gradient twice."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(1)
+    x = rng.normal(0, 1, (2, 8, 3, 6, 6)).astype(np.float32)
+    y = rng.normal(0, 1, (2, 8, 1)).astype(np.float32)
+    np.savez(tmp_path / "data.npz", x=x, y=y)
+    port = 33000 + int(rng.integers(0, 2000))
+    mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    net = _net()
+    for it in range(2):
+        ((net(torch.tensor(x[it])) - torch.tensor(y[it])) ** 2).mean().backward()
+    for k, p in net.named_parameters():
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.allclose(g0[k], p.grad, rtol=1e-5, atol=1e-6), k
