@@ -80,14 +80,14 @@ def conv_flops_per_image():
     return tot
 
 
-def build(args, device, rank):
+def build(args, device, rank, amp_dtype=torch.bfloat16):
     from dirhip import lds
     from dirhip.parallel import DataParallelEngine
     from dirhip.resnet import resnet50
     torch.manual_seed(0)
     model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
                      kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
-    engine = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
+    engine = DataParallelEngine(model, amp_dtype=amp_dtype, channels_last=True)
     engine.train()
     from dirhip.optim import Adam
     optimizer = Adam(engine.parameters(), lr=1e-3)          # torch.optim.Adam's arithmetic and state, one HIP launch (+ the bf16 weight operands)
@@ -130,6 +130,12 @@ def run_steps(engine, optimizer, batches, store, n_steps, epoch_len, epoch0, los
         if with_tail and (s + 1) % epoch_len == 0:
             epoch_tail(engine, ((bx, by) for bx, by, _ in batches), epoch, store)
             epoch += 1
+    rem = n_steps % epoch_len
+    if with_tail and rem:
+        # a last, shorter epoch: the reference's second pass touches every trained batch exactly once (train.py:269-281), so the
+        # timed region holds ONE tail forward per trained batch for any --steps (not only multiples of --epoch-len)
+        epoch_tail(engine, ((bx, by) for bx, by, _ in batches[:rem]), epoch, store)
+        epoch += 1
     return loss, epoch
 
 
@@ -236,7 +242,8 @@ def measured_peaks(device):
 
 FAMILIES = (("conv_igemm", "conv_igemm"), ("conv3x3_patch", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
             ("bn_", "batchnorm"), ("tail_", "tail"), ("fds_", "fds"), ("loss_", "loss"), ("scale_by_scalar", "loss"),
-            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("adam_step", "optimizer"), ("conv3x3_resident", "conv_igemm"), ("conv_ring", "conv_igemm"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"))
+            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("adam_step", "optimizer"), ("conv3x3_resident", "conv_igemm"), ("conv_ring", "conv_igemm"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"),
+            ("ncclDevKernel", "rccl_collective"), ("nccl", "rccl_collective"), ("rccl", "rccl_collective"))
 
 
 def in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch, steps=4):
@@ -396,7 +403,7 @@ def pmc_traffic(batch):
         return pmc_conv_parse.parse(tmp, batch)
 
 
-def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0):
+def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus_target=8):
     """SURVEY §8f-4 measured: can the real-file input pipeline feed the GPU loop? Synthetic JPEG files on local disk ->
     dirhip.datasets.IMDBWIKI (PIL decode + bilinear Resize to 224, host) in DataLoader workers -> (a) raw uint8 batches + ONE
     dir_augment_u8 launch on the GPU (train.py --gpu_augment; uint8 over PCIe) or (b) the host float transform chain of the
@@ -467,6 +474,13 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0):
         per_core_raw = 96 / (time.perf_counter() - t0)
         out["per_core_images_per_sec"] = {"decode_resize_uint8": per_core_raw, "decode_resize_host_float_chain": per_core,
                                           "cores_needed_for_consumer_uint8": consumer_img_s / per_core_raw}
+        host_cores = os.cpu_count() or 1
+        out["host_cores"] = host_cores
+        out["cores_needed_for_8_gpus"] = {"host_decode_plus_resize_uint8": n_gpus_target * consumer_img_s / per_core_raw,
+                                          "reference_host_float_chain": n_gpus_target * consumer_img_s / per_core,
+                                          "consumer_images_per_sec_per_gpu": consumer_img_s, "gpus": n_gpus_target,
+                                          "verdict": "host-bound at 8 GPUs on this box" if n_gpus_target * consumer_img_s / per_core_raw > host_cores
+                                                     else "the box's cores can feed 8 GPUs"}
         out["note"] = ("decode + Resize are host PIL in loader workers (no GPU JPEG decoder in this image); the rates are the loaders' own, not "
                        "overlapped with training; `value` of this bench uses HBM-resident synthetic batches")
         return out
@@ -551,7 +565,9 @@ def cpu_baseline(seconds_budget=20.0):
         if time.perf_counter() - t0 > seconds_budget * 0.45 or steps >= 32:
             break
     dt = time.perf_counter() - t0
-    res = {"value": steps * b / dt, "unit": "images/sec", "cores": cores, "kind": "reference" if live else "port",
+    res = {"value": steps * b / dt, "unit": "images/sec", "cores": cores, "kind": "reference" if live else "port", "batch": b,
+           "batch_note": f"B={b} (BASELINE configs[0]'s CPU-runnable batch), not the benchmarked B=256: a B=256 float32 step of the reference needs "
+                         "~60 GB of activations and minutes per step on the host",
            "sample": f"{steps} steps of B={b} 224x224 fp32 + {steps // epoch_len} epoch tails ({epoch_len} fwd passes + FDS update each), "
                      f"{source}, {dt:.1f} s"}
     del model, opt
@@ -605,6 +621,88 @@ def cpu_baseline(seconds_budget=20.0):
     return res
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): re-execute this very command line
+    under torch.distributed.run with N ranks on this node (one process per GPU, rendezvous on 127.0.0.1) and return its exit code.
+    The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form arrives with WORLD_SIZE set and is not touched."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: spawning {args.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def float32_mode_probe(device, args, loss_fn):
+    """The parity-exact configuration next to the benchmarked one: the SAME loop with `amp_dtype=None` — the whole
+    network on the exact-float32 MFMA kernels (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s = 1/16 of bf16), the mode that meets
+    north_star's 1e-5 loss bar — timed over a few steps, and its step-0 loss at B=256 against the reference's own float32 CPU run
+    (tests/golden/step0_b256.npz, written by tests/golden/gen_golden_r3.py from the reference; inputs regenerated from its seeds)."""
+    from dirhip import resnet as R
+    from dirhip.loss import weighted_l1_loss
+    from dirhip.optim import Adam
+    from dirhip.parallel import DataParallelEngine
+    from dirhip.train_loop import EpochFeatures
+    out = {"amp_dtype": None, "kernels": "dir_conv_f32_* (exact float32 MFMA), same fused autograd graph as the bf16 path"}
+    gpath = os.path.join(ROOT, "tests", "golden", "step0_b256.npz")
+    if os.path.isfile(gpath):
+        g = np.load(gpath, allow_pickle=False)
+        cfg = json.loads(str(g["config"]))
+        lt = lambda rng, n: np.clip(np.round(np.abs(rng.normal(0, 18, n)) + 20), 0, 120).astype(np.float32)      # noqa: E731
+        x = torch.randn(cfg["batch"], 3, 224, 224, generator=torch.Generator().manual_seed(cfg["seed_x"]))
+        rng = np.random.default_rng(cfg["seed_lab"])
+        y = torch.tensor(lt(rng, cfg["batch"])).view(-1, 1)
+        w = torch.tensor(rng.uniform(0.5, 1.5, cfg["batch"]).astype(np.float32)).view(-1, 1)
+        assert np.array_equal(y.numpy(), g["in_labels"]) and np.array_equal(w.numpy(), g["in_weights"])
+        torch.manual_seed(cfg["seed_model"])
+        model = R.resnet50(fds=True, bucket_num=cfg["bucket_num"], bucket_start=cfg["bucket_start"], start_update=cfg["start_update"],
+                           start_smooth=cfg["start_smooth"], kernel=cfg["kernel"], ks=cfg["ks"], sigma=cfg["sigma"], momentum=cfg["momentum"]).to(device)
+        eng = DataParallelEngine(model, amp_dtype=None, channels_last=True)
+        eng.train()
+        for ep in range(2):
+            rr = np.random.default_rng(cfg["seed_fds"] + ep)
+            lab = lt(rr, cfg["n_fds"])
+            feats = (np.abs(rr.normal(0, 1, (cfg["n_fds"], 2048))) * 0.5 + 0.01 * lab[:, None]).astype(np.float32)
+            model.FDS.update_last_epoch_stats(ep)
+            model.FDS.update_running_stats(torch.tensor(feats).to(device), torch.tensor(lab).to(device), ep)
+        pred, _ = eng(x.to(device), y.to(device), cfg["epoch"])
+        loss = float(weighted_l1_loss(pred, y.to(device), w.to(device)).item())
+        ref = float(g["ref_loss"])
+        out["step0_loss"] = loss
+        out["step0_loss_reference_float32_cpu"] = ref
+        out["loss_rel_err_vs_golden"] = abs(loss - ref) / abs(ref)
+        out["golden"] = f"tests/golden/step0_b256.npz (B={cfg['batch']}, epoch {cfg['epoch']}, FDS live; the reference's own modules on the CPU)"
+        del model, eng, pred
+    else:
+        out["loss_rel_err_vs_golden"] = None
+    # ---- throughput of the same loop (train steps + one tail forward per trained batch) in float32 mode
+    saved = (args.epoch_len,)
+    steps, epoch_len = 4, 2
+    args.epoch_len = epoch_len
+    try:
+        model, engine, optimizer, batches = build(args, device, 0, amp_dtype=None)
+    finally:
+        args.epoch_len, = saved
+    store = EpochFeatures(epoch_len * args.batch, 2048, device)
+    run_steps(engine, optimizer, batches, store, 2, epoch_len, 2, loss_fn)           # set-up + warm-up
+    dt, (loss, _) = timed(lambda: run_steps(engine, optimizer, batches, store, steps, epoch_len, 3, loss_fn), device, 1)
+    dt_train, _ = timed(lambda: run_steps(engine, optimizer, batches, store, steps, epoch_len, 5, loss_fn, with_tail=False), device, 1)
+    assert np.isfinite(float(loss.item()))
+    out.update({"images_per_sec": steps * args.batch / dt, "ms_per_step": dt / steps * 1e3, "train_only_images_per_sec": steps * args.batch / dt_train,
+                "train_only_ms_per_step": dt_train / steps * 1e3, "steps": steps, "batch": args.batch,
+                "achieved_TFLOPs_train_only": steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12, "peak_f32_mfma_TFLOPs": 157.3,
+                "frac_of_f32_mfma_peak_train_only": steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / 157.3})
+    del model, engine, optimizer, batches, store
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -618,13 +716,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-pipeline", action="store_true", help="skip the real-file input pipeline probe (synthetic JPEGs through the DataLoader)")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--no-float32-mode", action="store_true", help="skip the float32 (parity-exact) mode leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic stays null)")
+    ap.add_argument("--full-probes", action="store_true", help="N > 1 only: rank 0 also runs the per-layer / FDS-kernel / input-pipeline probes "
+                    "that the N = 1 line carries (by default an N > 1 line carries roofline, step breakdown, peaks, comm, cpu_baseline)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args))
     args.epoch_len = max(1, min(args.epoch_len, args.steps))      # at least one epoch tail inside the timed region
     from dirhip.parallel import init_distributed
     rank, world, local_rank = init_distributed(backend=args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the hot path has no CPU fallback)")
     device = torch.device("cuda", 0 if args.share_gpu else local_rank)
@@ -653,8 +757,8 @@ def main():
                         device, world)
 
     images = args.steps * args.batch * world
-    n_tails = args.steps // args.epoch_len
-    flops = args.steps * args.batch * FLOP_FWD_BWD + n_tails * args.epoch_len * args.batch * FLOP_FWD   # per GPU
+    n_tails = -(-args.steps // args.epoch_len)
+    flops = args.steps * args.batch * FLOP_FWD_BWD + args.steps * args.batch * FLOP_FWD   # per GPU: one tail forward per trained batch
     result = {
         "metric": "images/sec ResNet-50+FDS IMDB-WIKI 224x224 (train loop incl. FDS epoch tail)",
         "value": images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -662,9 +766,11 @@ def main():
         "dtype": "bf16", "data": "synthetic" if not args.share_gpu else "synthetic (TEST RUN: all ranks share one GPU, number meaningless)",
         "config": {"workload": "BASELINE configs[1]: IMDB-WIKI-DIR ResNet-50 + LDS + FDS (ks=5, sigma=2), bf16 conv stack (own MFMA kernels: stem, "
                                "implicit-GEMM fwd/dgrad/wgrad) + fused HIP BatchNorm / join / pool nodes, fp32 fused pool-FDS-linear tail + loss, "
-                               "batch=256 per MI355X, l1 loss, Adam 1e-3", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                   "epoch_len_steps": args.epoch_len, "epoch_tails_in_timed_region": n_tails, "parallelism": f"dp{world}",
-                   "final_loss": loss_val},
+                               "batch=256 per MI355X, l1 loss, Adam 1e-3" + ("" if world == 1 else f"; BASELINE configs[2] form: {world} ranks, RCCL "
+                               "gradient all-reduce per step + FDS statistic all-reduce per epoch tail"),
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "epoch_len_steps": args.epoch_len, "epoch_tails_in_timed_region": n_tails, "tail_forward_batches_in_timed_region": args.steps,
+                   "tail_batches_per_trained_batch": 1.0, "parallelism": f"dp{world}", "final_loss": loss_val},
         "train_only_images_per_sec": images / dt_train,
         # whole-loop MFMA fraction (24.287 GFLOP per trained image + 8.174 per tail-forward image over the wall clock)
         "roofline_loop": {"bound": "mfma", "kernel": "whole train loop per GPU: ResNet-50 fwd+bwd (+ fwd-only epoch tail)",
@@ -673,17 +779,27 @@ def main():
                           "train_only_frac": args.steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / PEAK_BF16_TFLOPS},
     }
     result["roofline"] = dict(result["roofline_loop"], traffic=None)      # replaced below by the dominant kernel's when measured
+    # ---- measurements that still need every rank (collectives inside the steps): communication report, in-situ kernel times
     if world > 1:
         result["comm"] = comm_probe(engine, optimizer, batches, loss_fn, epoch, device, world)
-    if rank == 0 and world == 1 and not args.no_kernel_rooflines:
+    fam = None
+    if not args.no_kernel_rooflines:
         fam = in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch)
         log("in-situ kernel breakdown done")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    # ---- rank 0 alone from here on (the other ranks have left; nothing below communicates)
+    full = world == 1 or args.full_probes
+    if fam is not None:
         del engine, optimizer, batches, store
         torch.cuda.empty_cache()
         peaks = measured_peaks(device)
         log("measured peaks done")
         conv_fwd_flop = conv_flops_per_image() * args.batch
-        busy = sum(f["us_per_step"] for f in fam.values())
+        busy = sum(f["us_per_step"] for k, f in fam.items() if k != "rccl_collective")
         ig = fam.get("conv_igemm", {"us_per_step": float("nan"), "launches_per_step": 0})
         alg_flop = 2.0 * conv_fwd_flop                                      # forward + data gradient of the 52 layers
         ach = alg_flop / (ig["us_per_step"] * 1e-6) / 1e12
@@ -692,7 +808,7 @@ def main():
         # data-gradient configuration of the 52 layers once, isolated — after the timed region; if rocprofv3 is not usable here,
         # the last committed pass is quoted instead and `traffic` stays null
         traffic, traffic_note = None, None
-        if not args.no_pmc:
+        if not args.no_pmc and full:
             try:
                 pm = pmc_traffic(args.batch)
                 traffic = pm["traffic_bytes_per_launch"]
@@ -704,7 +820,7 @@ def main():
             except Exception as e:                                      # noqa: BLE001
                 log(f"PMC traffic passes failed ({type(e).__name__}: {e}); quoting the committed pass")
         if traffic_note is None:
-            for name in ("r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
+            for name in ("r04_conv_pmc_traffic.json", "r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.isfile(tpath):
                     tj = json.load(open(tpath))
@@ -712,12 +828,21 @@ def main():
                                     "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_step", 0) / max(1, tj.get("launches_per_step", 1)),
                                     "launches_per_step_in_that_pass": tj.get("launches_per_step")}
                     break
+        mfma_busy = None
+        for name in ("r04_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+            mpath = os.path.join(ROOT, "profiles", name)
+            if os.path.isfile(mpath):
+                mj = json.load(open(mpath))
+                mfma_busy = {"source": f"profiles/{name} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, isolated launches)",
+                             **{k: v for k, v in mj.items() if not isinstance(v, (list, dict))}}
+                break
         result["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_patch_kernel (hand-written MFMA implicit GEMM): every forward "
-                                       "and data-gradient launch of the 52 conv layers of one training step, in situ; their store loops also carry "
-                                       "the shortcut-gradient adds, ReLU masks and 43 of the 52 BatchNorm backward reductions",
+            "bound": "mfma", "kernel": "conv_igemm_kernel / conv_igemm_dma_kernel / conv_igemm_big_kernel / conv3x3_patch_kernel (hand-written MFMA implicit "
+                                       "GEMM): every forward and data-gradient launch of the 52 conv layers of one training step, in situ; their store "
+                                       "loops also carry the shortcut-gradient adds, ReLU masks and 43 of the 52 BatchNorm backward reductions",
             "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
             "frac_of_measured_peak": ach / peaks["bf16_mfma_TFs"], "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_detail": traffic_note,
+            "mfma_busy": mfma_busy,
             "launches_per_step": ig["launches_per_step"], "avg_launch_us": ig["us_per_step"] / max(1.0, ig["launches_per_step"]),
             "algorithmic_flop_per_step": alg_flop, "ms_per_step_in_this_kernel": ig["us_per_step"] / 1e3,
             "method": "device time of every conv_igemm* / conv3x3_patch* launch over 4 whole training steps (profiler kernel trace), algorithmic "
@@ -728,7 +853,7 @@ def main():
         kr = []
         if "conv_wgrad" in fam:
             a = conv_fwd_flop / (fam["conv_wgrad"]["us_per_step"] * 1e-6) / 1e12
-            kr.append({"kernel": "conv_wgrad_kernel + reduce (weight gradients of the 52 layers), in situ", "bound": "mfma", "ms": fam["conv_wgrad"]["us_per_step"] / 1e3,
+            kr.append({"kernel": "conv_wgrad_* kernels + reduce (weight gradients of the 52 layers), in situ", "bound": "mfma", "ms": fam["conv_wgrad"]["us_per_step"] / 1e3,
                        "algorithmic_flop": conv_fwd_flop, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_BF16_TFLOPS,
                        "frac_of_measured_peak": a / peaks["bf16_mfma_TFs"]})
         if "batchnorm" in fam:
@@ -746,28 +871,30 @@ def main():
             a = alg / (fam["tail"]["us_per_step"] * 1e-6) / 1e9
             kr.append({"kernel": "dir_tail_fwd + dir_tail_bwd (pool -> FDS calibrate -> linear), in situ", "bound": "hbm", "ms": fam["tail"]["us_per_step"] / 1e3,
                        "algorithmic_bytes": alg, "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS})
-        result["kernel_rooflines"] = kr + fds_kernel_rooflines(device)
+        result["kernel_rooflines"] = kr + (fds_kernel_rooflines(device) if full else [])
         for r in result["kernel_rooflines"]:
             if r.get("unit") == "GB/s" and "frac_of_measured_peak" not in r:
                 r["frac_of_measured_peak"] = r["achieved"] / peaks["stream_read_GBs"]
         log("kernel rooflines done")
-        rows = conv_layer_probe(device, args.batch)
-        result["conv_layers"] = {"columns": ["cin", "cout", "k", "stride", "H", "count", "kind", "us", "roofline_us", "launches"],
-                                 "rows": [[*r[:7], round(r[7], 1), round(r[8], 1), r[9]] for r in rows],
-                                 "sum_ms": {kind: sum(r[7] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
-                                 "sum_roofline_ms": {kind: sum(r[8] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
-                                 "note": "isolated launches, inputs rotated over > 256 MB of distinct buffers; roofline_us = max(FLOP / 2.5 PF, bytes / 8 TB/s)"}
         result["peaks"] = peaks
+        if full:
+            rows = conv_layer_probe(device, args.batch)
+            result["conv_layers"] = {"columns": ["cin", "cout", "k", "stride", "H", "count", "kind", "us", "roofline_us", "launches"],
+                                     "rows": [[*r[:7], round(r[7], 1), round(r[8], 1), r[9]] for r in rows],
+                                     "sum_ms": {kind: sum(r[7] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
+                                     "sum_roofline_ms": {kind: sum(r[8] * r[5] for r in rows if r[6].startswith(kind)) / 1e3 for kind in ("fwd", "dgrad", "wgrad")},
+                                     "note": "isolated launches, inputs rotated over > 256 MB of distinct buffers; roofline_us = max(FLOP / 2.5 PF, bytes / 8 TB/s)"}
+            log("conv layer probe done")
         # ---- what the training step could cost at best with THIS algorithm (training-mode BatchNorm = a grid-wide reduction between
         # every convolution and its consumer, so no kernel can be fused across it): the sum over its kernels of max(FLOP / MFMA peak,
         # algorithmic bytes / HBM peak), at the nominal peaks and at the peaks measured on this box
         def conv_floor(pf, bw):
             tot = 0.0
-            for cin, cout, k, st, h, cnt, kind, *_ in rows:
+            for cin, cout, k, st, h, cnt in RESNET50_CONVS:
                 ho = (h + 2 * (k // 2) - k) // st + 1
                 flop = 2.0 * args.batch * ho * ho * cout * cin * k * k
                 nbytes = (args.batch * h * h * cin + args.batch * ho * ho * cout) * 2
-                tot += cnt * max(flop / pf, nbytes / bw)
+                tot += 3 * cnt * max(flop / pf, nbytes / bw)                 # forward, data gradient, weight gradient
             return tot * 1e3
         bn_bytes = (5 * 11.11e6 + 2 * 3.11e6) * args.batch * 2
         stem_bytes = args.batch * (224 * 224 * 3 * 2 * 2 + 112 * 112 * 64 * 2 * 6 + 56 * 56 * 64 * (2 * 3 + 1 * 3))   # image x2, stem map x6, pooled map / indices x3
@@ -781,20 +908,25 @@ def main():
                                    "frac_of_measured_peak_floor": floors["measured_on_this_box"]["total_ms"] / step_ms,
                                    "note": "floor = sum over the step's kernels of max(FLOP / bf16 MFMA peak, algorithmic bytes / HBM peak): per conv layer and "
                                            "direction, BatchNorm family bytes (SURVEY 8d), stem + stem tail, optimizer; batch-statistics BatchNorm forbids fusing across it"}
-        log("conv layer probe done")
-    if rank == 0 and world == 1 and not args.no_input_pipeline:
+    else:
+        del engine, optimizer, batches, store
+        torch.cuda.empty_cache()
+    if not args.no_float32_mode:
         try:
-            result["input_pipeline"] = input_pipeline_probe(device, result["value"], args.batch)
+            result["float32_mode"] = float32_mode_probe(device, args, loss_fn)
+            log("float32 (parity-exact) mode leg done")
+        except Exception as e:                                          # noqa: BLE001  (a measurement, never a reason to lose the bench line)
+            result["float32_mode"] = {"error": f"{type(e).__name__}: {e}"}
+    if full and not args.no_input_pipeline:
+        try:
+            result["input_pipeline"] = input_pipeline_probe(device, result["value"] / world, args.batch, n_gpus_target=8)
             log("input pipeline probe done")
         except Exception as e:                                          # noqa: BLE001  (a measurement, never a reason to lose the bench line)
             result["input_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         log("cpu baseline done")
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -87,6 +87,7 @@ class FDS(nn.Module):
         # data-parallel: merge the epoch statistics over this group (None = default group).
         self.sync_across_ranks = True
         self.process_group = None
+        self.force_collectives = False     # tests: run the cross-rank merge in a one-rank group too (parallel.DataParallelEngine)
         self._scale = None
         self._scale_key = None
 
@@ -177,7 +178,8 @@ class FDS(nn.Module):
     def _world(self):
         import torch.distributed as dist
         if self.sync_across_ranks and dist.is_available() and dist.is_initialized():
-            return dist.get_world_size(self.process_group)
+            w = dist.get_world_size(self.process_group)
+            return 2 if (w == 1 and self.force_collectives) else w          # (only ever compared with 1: "is there a merge step")
         return 1
 
     def local_stats(self, features, labels):

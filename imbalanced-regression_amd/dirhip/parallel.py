@@ -83,11 +83,15 @@ class DataParallelEngine(nn.Module):
     the gradient exchange is driven by autograd hooks and completes before ``backward()`` returns."""
 
     def __init__(self, module, process_group=None, bucket_mb=32, amp_dtype=None, channels_last=False,
-                 broadcast_from_rank0=True):
+                 broadcast_from_rank0=True, force_collectives=False):
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives: run the N > 1 machinery (parameter broadcast, bucket hooks, the all-reduces, the FDS statistic merge) in a
+        # process group of ONE rank too — every collective then is the identity, which is how the RCCL path is executed and checked
+        # on a one-GPU box (tests/test_hip_rccl.py); never set by the training entry points
+        self._comm = bool(self.world > 1 or (force_collectives and dist.is_initialized()))
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last
@@ -105,11 +109,11 @@ class DataParallelEngine(nn.Module):
         # zero_grad): the bucket then holds the previous, already averaged gradient, and SUM over ranks of (mean_1 + local_2 / world)
         # would count mean_1 `world` times. That pass sums the unscaled gradients and scales the buckets afterwards instead
         # (SUM(mean_1 + local_2) / world = mean_1 + mean_2, what AVG gives on RCCL); `bucket_scale_kernels` counts those passes.
-        self._native_avg = bool(self.world > 1 and dist.get_backend(process_group) == "nccl")
+        self._native_avg = bool(self._comm and dist.get_backend(process_group) == "nccl")
         self._accumulating = False
         if channels_last:
             self.module.to(memory_format=torch.channels_last)
-        if self.world > 1 and broadcast_from_rank0:
+        if self._comm and broadcast_from_rank0:
             with torch.no_grad():
                 for t in list(self.module.parameters()) + list(self.module.buffers()):
                     dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group else 0,
@@ -117,10 +121,12 @@ class DataParallelEngine(nn.Module):
         fds = getattr(self.module, "FDS", None)
         if fds is not None:
             fds.process_group = process_group
+            if force_collectives:
+                fds.force_collectives = True
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, inputs, *args, **kwargs):
-        if self.training and torch.is_grad_enabled() and (self.world > 1 or inputs.is_cuda):
+        if self.training and torch.is_grad_enabled() and (self._comm or inputs.is_cuda):
             self._prepare_buckets()         # (one process: the buckets are just persistent gradient storage — static addresses for the
                                             #  optimizer kernel's table, no allocation per gradient and step; no hooks, no collective)
         if self.channels_last and inputs.dim() == 4:
@@ -130,7 +136,7 @@ class DataParallelEngine(nn.Module):
                 out = self.module(inputs, *args, **kwargs)
         else:
             out = self.module(inputs, *args, **kwargs)
-        if self.world > 1 and not self._native_avg and self.training and torch.is_grad_enabled() and not self._accumulating:
+        if self._comm and not self._native_avg and self.training and torch.is_grad_enabled() and not self._accumulating:
             inv = 1.0 / self.world
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(t, torch.Tensor) and t.requires_grad:
@@ -159,7 +165,7 @@ class DataParallelEngine(nn.Module):
             for bi, b in enumerate(self._buckets):
                 for pi, p in enumerate(b.params):
                     self._bucket_of[id(p)] = (bi, pi)
-                    if self.world > 1:
+                    if self._comm:
                         self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
                     # the gradient kernels write into the bucket — unless the parameter still HOLDS a gradient (accumulation over
                     # several backward passes, zero_grad(set_to_none=False)): the slot is that gradient, so the kernel gets a new tensor
@@ -170,7 +176,7 @@ class DataParallelEngine(nn.Module):
             b.pending = len(b.params)
             b.work = None
         self._callback_queued = False
-        self._accumulating = bool(self.world > 1 and any(p.grad is not None for p in params))
+        self._accumulating = bool(self._comm and any(p.grad is not None for p in params))
 
     def _on_grad_ready(self, p):
         if not self._callback_queued:
@@ -227,7 +233,7 @@ class DataParallelEngine(nn.Module):
     def comm_report(self):
         """Observability of the N > 1 path (bench.py): ranks, bucket sizes, and — when ``measure_comm`` was on — the time the compute
         stream spent between the last backward kernel and the last collective (= communication NOT hidden behind the backward)."""
-        rep = {"ranks": self.world, "backend": dist.get_backend(self.process_group) if self.world > 1 else None,
+        rep = {"ranks": self.world, "backend": dist.get_backend(self.process_group) if self._comm else None,
                "reduce_op": "avg (in the collective)" if self._native_avg else "sum of gradients pre-scaled by 1/ranks at the network output",
                "buckets_MB": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in (self._buckets or [])],
                "grad_copies": self.stats["grad_copies"], "bucket_scale_kernels": self.stats["bucket_scale_kernels"], "steps": self.stats["steps"]}

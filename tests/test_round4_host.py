@@ -26,3 +26,18 @@ def test_adam_fallback_with_closure_takes_the_step_and_returns_the_loss():
     assert la is not None and float(la.detach()) == float(lb.detach())
     assert torch.equal(p, q) and not torch.equal(p.detach(), torch.zeros_like(p))
     assert float(a.state[p]["step"]) == 1.0
+
+
+def test_bench_self_spawns_its_ranks_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` (no torchrun around it, no WORLD_SIZE) must start its own two ranks instead of
+    dying on an assert. Without a GPU each rank gets as far as the process-group rendezvous (gloo here) and then stops at the
+    "needs an AMD GPU" gate — which is what this CPU test looks for; on the GPU box tests/test_hip_dropin.py runs it for real."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only form of the launcher test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert "spawning 2 ranks" in p.stderr, p.stderr[-2000:]
+    assert p.stderr.count("bench.py needs an AMD GPU") >= 1, p.stderr[-2000:]          # the ranks came up and met the GPU gate
+    assert "but the launcher started" not in p.stderr and "AssertionError" not in p.stderr
+    assert p.returncode != 0                                                          # no GPU: the failure is loud, not a fake line
