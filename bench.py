@@ -209,9 +209,12 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def measured_peaks(device):
-    """STREAM-style HBM bandwidth and MFMA issue peaks of this box (csrc/dir_probe.hip), HIP events on the launch stream."""
+    """STREAM-style HBM bandwidth and MFMA issue peaks of this box (tools/csrc/dir_probe.hip -> tools/lib/libdir_hip_tools.so: the
+    probes are not part of the product library), HIP events on the launch stream."""
     from dirhip import _lib as L
-    lib = L.lib()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import toolslib
+    lib = toolslib.lib()
     st = L.stream_ptr(device)
     nbytes = 1 << 30
     src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
@@ -242,7 +245,7 @@ def measured_peaks(device):
 
 FAMILIES = (("conv_igemm", "conv_igemm"), ("conv3x3_patch", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_", "stem"), ("bn_relu_maxpool", "stem_tail"),
             ("bn_", "batchnorm"), ("tail_", "tail"), ("fds_", "fds"), ("loss_", "loss"), ("scale_by_scalar", "loss"),
-            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("adam_step", "optimizer"), ("conv3x3_resident", "conv_igemm"), ("conv_ring", "conv_igemm"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"),
+            ("conv_prep_weights", "weight_prep"), ("FusedAdam", "optimizer"), ("adam_step", "optimizer"), ("Cijk_", "library_gemm"), ("miopen", "library_miopen"),
             ("ncclDevKernel", "rccl_collective"), ("nccl", "rccl_collective"), ("rccl", "rccl_collective"))
 
 

@@ -15,7 +15,7 @@
 
 namespace {
 
-int g_bn_cap_total = 768;
+constexpr int BN_CAP_TOTAL = 768;   // workgroups per streaming launch = 3 per CU (256..4096 swept in round 1, 512..2048 again in round 3)
 
 struct BnGeom {
     int ct;             // channel tile handled by one workgroup column (<= 256 for bf16, <= 128 for f32)
@@ -24,9 +24,9 @@ struct BnGeom {
     int ctiles;         // C / ct
     int rblocks;        // row blocks (grid.x)
     int chunk;          // apply passes only: 0 = persistent sweep (grid.x = rblocks, stride rblocks * rpi); > 0 = rows per workgroup,
-                        // consecutive (grid.x = ceil(M / chunk)): short-lived workgroups in address order (dir_bn_set_apply_chunk)
+                        // consecutive (grid.x = ceil(M / chunk)): short-lived workgroups in address order (BN_APPLY_CHUNK)
 };
-int g_bn_apply_chunk = 0;
+constexpr int BN_APPLY_CHUNK = 0;    // compile-time measurement knob (round 3: 0.9998 at 16 KB chunks, worse at 8 / 32 KB): 0 = persistent sweep
 
 struct BnWalk { int64_t row, stride, end; };
 __device__ __forceinline__ BnWalk bn_walk(const BnGeom& g, int64_t M, int tr) {
@@ -49,16 +49,16 @@ BnGeom bn_geom(int64_t M, int C) {
     g.rpi = DIR_TPB / g.tpr;
     g.ctiles = C / g.ct;
     int64_t want = (M + (int64_t)g.rpi * 4 - 1) / ((int64_t)g.rpi * 4);   // >= 4 row iterations per workgroup
-    const int cap_total = g_bn_cap_total;               // workgroups = 3 per CU (256..4096 swept in round 1, 512..2048 again in round 3)
+    const int cap_total = BN_CAP_TOTAL;
     int64_t cap = cap_total / g.ctiles; if (cap < 1) cap = 1;   // <= 768/ctiles partial rows per channel
     g.rblocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     g.chunk = 0;
     return g;
 }
-// geometry of an apply pass: the sweep of bn_geom, or (dir_bn_set_apply_chunk(iters)) `iters` consecutive row groups per workgroup
+// geometry of an apply pass: the sweep of bn_geom, or (BN_APPLY_CHUNK = iters > 0) `iters` consecutive row groups per workgroup
 inline BnGeom bn_apply_geom(BnGeom g, int64_t M) {
-    if (g_bn_apply_chunk > 0) {
-        g.chunk = g_bn_apply_chunk * g.rpi;
+    if (BN_APPLY_CHUNK > 0) {
+        g.chunk = BN_APPLY_CHUNK * g.rpi;
         g.rblocks = (int)((M + g.chunk - 1) / g.chunk);
     }
     return g;
@@ -655,9 +655,9 @@ bn_bwd_join_apply_kernel(const T* __restrict__ gout, const T* __restrict__ x, co
     }
 }
 
-// A/B switch for tools and tests (process-wide, default 0: measured neutral, profiles/r03_ab_in_process.txt): 1 = the training-mode forward and the backward finalize inside their
-// apply pass (fold + apply), 0 = fold (long lists) + finalize launch + apply as in round 2.
-int g_bn_fused_finalize = 0;
+// Compile-time measurement knob (round 3: measured neutral, profiles/r03_ab_in_process.txt): true = the training-mode forward and the
+// backward finalize inside their apply pass (fold + apply), false = fold (long lists) + finalize launch + apply.
+constexpr bool BN_FUSED_FINALIZE = false;
 
 struct BnWs { float* partial; float* coef; double* folded; size_t bytes; };
 template <int VEC> BnWs bn_ws(void* base, int64_t M, int C) {
@@ -753,7 +753,7 @@ int fwd_impl(const void* x_, const void* res_, void* y_, int64_t M, int C, const
     constexpr int VEC = Vec<T>::N;
     BnWs w = bn_ws<VEC>(ws, M, C);
     DIR_RETURN_IF(ws_bytes < w.bytes, DIR_EWORKSPACE);
-    if (training && g_bn_fused_finalize) {
+    if (training && BN_FUSED_FINALIZE) {
         // statistics (own pass, or the producing convolution's partial list) -> fold to <= BN_FOLD_ROWS float64 rows -> the apply
         // pass finalizes per channel tile itself (no finalize launch)
         const float* part = ext_partial;
@@ -795,7 +795,7 @@ int bwd_impl(const void* dout_, const void* x_, const void* out_, void* dx_, voi
     // mask source: saved output if given, else recomputed from x (only valid when no residual was added)
     const int mask = !relu ? 0 : (out ? 1 : 2);
     BnFinB fin{};
-    if (g_bn_fused_finalize) {
+    if (BN_FUSED_FINALIZE) {
         const float* part = ext_partial;
         int prow = ext_rows;
         if (part) { DIR_RETURN_IF(mask == 1, DIR_EINVAL); }
@@ -893,11 +893,6 @@ extern "C" int dir_bn_bwd_join(const void* g, const void* x, const void* r, void
                                 dgamma_r, dbeta_r, workspace, workspace_bytes, dir_s(stream));
 }
 
-extern "C" int dir_bn_set_grid_cap(int cap) { const int prev = g_bn_cap_total; if (cap >= 64) g_bn_cap_total = cap; return prev; }
-
-extern "C" int dir_bn_set_apply_chunk(int iters) { const int prev = g_bn_apply_chunk; g_bn_apply_chunk = iters < 0 ? 0 : (iters > 64 ? 64 : iters); return prev; }
-
-extern "C" int dir_bn_set_fused_finalize(int mode) { const int prev = g_bn_fused_finalize; g_bn_fused_finalize = mode ? 1 : 0; return prev; }
 
 extern "C" size_t dir_bn_workspace(int dtype, int64_t M, int C) {
     if (!bn_shape_ok(dtype, M, C)) return 0;

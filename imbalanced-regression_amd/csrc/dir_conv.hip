@@ -1087,162 +1087,6 @@ conv3x3_patch_kernel(ConvP p) {
     cv_epilogue<BN, false, NST == 1 ? 4 : 2>(pe, acc, smem, t, m0, n0, mt);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1, 64 -> 64 channels on 56^2 maps (conv2 of stage 1, and its data gradient), WEIGHTS RESIDENT:
-// these three layers (x forward, data gradient and epoch-tail forward) sat furthest from their roofline (108 / 90 us against
-// 34 us of HBM time): a patch-staged workgroup does 72 MFMAs per wavefront between a patch load, NINE weight-slice round trips
-// (8 KB each, one barrier pair per tap) and a store drain — 7168 workgroups whose latency chains four co-resident workgroups only
-// partly hide. Here ONE persistent workgroup per CU keeps all nine taps of the 64 x 64 weights in LDS (72 KB, loaded once), walks
-// its chunks of two image rows, and per chunk does: [patch of chunk j has landed] -> barrier -> DMA of chunk j + 1's patch into the
-// other patch buffer -> 9 taps x 8 MFMAs straight out of LDS (no weight traffic, no per-tap barrier) -> epilogue of chunk j.
-// The next patch's DMA is issued BEFORE the epilogue's stores, so the counted vmcnt wait that precedes the next chunk's MFMAs
-// covers the DMA and not the stores (gfx950 retires loads and stores through ONE in-order counter): nothing ever waits for a
-// store to be acknowledged. Same MFMA order per output element as conv3x3_patch_kernel: bit-identical results and statistics.
-// LDS: weights 73 728 + two patch buffers 65 536 + the epilogue's staging tile and column partials 20 480 = 159 744 bytes.
-template <bool LEAN>
-__global__ void __launch_bounds__(DIR_TPB)
-conv3x3_resident_kernel(ConvP p, int nchunks) {
-    using G = CpGeom<56>;
-    constexpr int BN = 64, MI = 1, NI = 2, WM = 32, B_BYTES = BN * CV_ROWB;
-    constexpr int W_BYTES = 9 * B_BYTES;                          // 73 728
-    // vmcnt is per wavefront and in issue order: behind the next patch's DMA every wavefront issues the epilogue's row stores — 4
-    // (CV_BM / (DIR_TPB / 8)), or 3 for the wavefronts whose last row lies in the tile's padding (rows 112..127: the lean store
-    // loop skips the instruction) — and wavefronts 0-1 one statistics store. Waiting for "all but the newest 3" therefore covers
-    // the DMA for every wavefront and never a store that has not been issued long ago.
-    constexpr int NSTORE = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Wres = smem;
-    unsigned char* Pat = smem + W_BYTES;
-    unsigned char* Stage = smem + W_BYTES + 2 * G::PATCH;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    typedef __attribute__((address_space(3))) unsigned char* cp_lds_t;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(cp_lds_t)smem;
-    const cp_u32x4 rs_x = cp_rsrc(p.x, (uint32_t)(p.N * p.H * p.W) * (uint32_t)p.Cin * 2u);
-    const int K = p.KT * CV_BK;
-    const cp_u32x4 rs_w = cp_rsrc(p.w, (uint32_t)p.Cout * (uint32_t)K * 2u);
-    const int lr = lane >> 3, lc = lane & 7;
-
-    // ---- the nine weight slices, once: piece i of this wave = rows wave*16 + 8 i + lr of tap `tap` (as CP_ISSUE_B)
-    {
-        int woff[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int chunk = lc ^ ((lane >> 4) | ((i & 1) << 2));
-            woff[i] = ((wave * 16 + 8 * i + lr) * K + chunk * 8) * 2;
-        }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                cp_dma16(rs_w, lds0 + (uint32_t)(tap * B_BYTES + wave * 2048 + i * 1024), woff[i], tap * CV_BK * 2);
-    }
-    // ---- per-lane patch roles and fragment addresses (chunk independent)
-    int prel[G::PPW];                                             // source chunk of the lane relative to pixel (h0 - 1, -1); CV_OOB = border
-#pragma unroll
-    for (int i = 0; i < G::PPW; ++i) {
-        const int q = wave + 4 * i;
-        const int row = q * 8 + lr;
-        const int pr = row / G::P, pc = row - pr * G::P;
-        prel[i] = (pc >= 1 && pc <= 56) ? ((pr * 56 + pc) * 64 + (lc ^ ((row >> 1) & 7)) * 8) * 2 : CV_OOB;   // (rows outside the image: below)
-    }
-    uint32_t arow[3], az[3];
-    {
-        const int k = wm * WM + frow;
-        const int i = k / 56, w = k - i * 56;
-        const int pp0 = k < G::KPIX ? i * G::P + w : 0;
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) { arow[s2] = (uint32_t)(pp0 + s2) * CV_ROWB; az[s2] = (uint32_t)(((pp0 + s2) >> 1) & 7); }
-    }
-    uint32_t bf[NI][4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int row = ni * 32 + frow;
-            bf[ni][kk] = row * CV_ROWB + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) << 4);
-        }
-    // patch rows pr = 0 / 3 fall outside the image for the first / last chunk of an image: those pieces load zeros
-    auto issue_patch = [&](int chunk, int ps) {
-        const int n_img = chunk / G::CPI, h0 = (chunk - n_img * G::CPI) * G::RB;
-        const int xbase = (((n_img * 56 + h0 - 1) * 56 - 1) * 64) * 2;
-#pragma unroll
-        for (int i = 0; i < G::PPW; ++i) {
-            const int q = wave + 4 * i;
-            const int pr = (q * 8) / G::P;                        // (a piece never straddles patch rows: P = 64 is a multiple of 8)
-            const int hi = h0 - 1 + pr;
-            const bool in = prel[i] != CV_OOB && hi >= 0 && hi < 56;
-            cp_dma16(rs_x, lds0 + (uint32_t)(W_BYTES + ps * G::PATCH + q * 1024), in ? xbase + prel[i] : CV_OOB, 0);
-        }
-    };
-    const int first = blockIdx.x, step = gridDim.x;
-    if (first >= nchunks) { cp_dma_wait(); return; }
-    issue_patch(first, 0);
-    f32x16 acc[MI][NI];
-    int ps = 0;
-    for (int chunk = first; chunk < nchunks; chunk += step) {
-        // patch `chunk` (and, the first time, the weights) has landed for this wave: everything older than the previous chunk's
-        // NSTORE row stores (+ the statistics store) — those stay in flight
-        if (chunk == first) cp_dma_wait();
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORE - 1) : "memory");
-        __syncthreads();                                          // ... for everybody; the other patch buffer and the staging tile are free
-        if (chunk + step < nchunks) issue_patch(chunk + step, ps ^ 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-        // One wavefront per SIMD: nobody else hides the LDS latency of the fragment reads, so they are software-pipelined by hand —
-        // the twelve fragments of tap t + 1 are read (into the other register set) before the eight MFMAs of tap t are issued.
-        const unsigned char* pb = Pat + ps * G::PATCH;
-        bf16x8 fa[2][4], fb[2][NI][4];
-        auto read_tap = [&](auto tap_c, auto set_c) {
-            constexpr int tap = decltype(tap_c)::value, set = decltype(set_c)::value;
-            constexpr int r_ = tap / 3, s_ = tap % 3;
-            const unsigned char* ab = pb + r_ * (G::P * CV_ROWB);
-            const unsigned char* bbs = Wres + tap * B_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                fa[set][kk] = *reinterpret_cast<const bf16x8*>(ab + arow[s_] + ((((uint32_t)(kk * 2 + fhalf)) ^ az[s_]) << 4));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) fb[set][ni][kk] = *reinterpret_cast<const bf16x8*>(bbs + bf[ni][kk]);
-            }
-        };
-        auto mfma_tap = [&](auto set_c) {
-            constexpr int set = decltype(set_c)::value;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][ni][kk], fa[set][kk], acc[0][ni], 0, 0, 0);
-        };
-        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
-#define RS_TAP(T_) std::integral_constant<int, T_>{}
-#define RS_SB __builtin_amdgcn_sched_barrier(0)          /* pins "reads of tap t + 1, then MFMAs of tap t" (the scheduler otherwise sinks the reads) */
-        read_tap(RS_TAP(0), I0{}); RS_SB;
-        read_tap(RS_TAP(1), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
-        read_tap(RS_TAP(2), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
-        read_tap(RS_TAP(3), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
-        read_tap(RS_TAP(4), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
-        read_tap(RS_TAP(5), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
-        read_tap(RS_TAP(6), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
-        read_tap(RS_TAP(7), I1{}); RS_SB; mfma_tap(I0{}); RS_SB;
-        read_tap(RS_TAP(8), I0{}); RS_SB; mfma_tap(I1{}); RS_SB;
-        mfma_tap(I0{});
-#undef RS_SB
-#undef RS_TAP
-        const int n_img = chunk / G::CPI, h0 = (chunk - n_img * G::CPI) * G::RB;
-        const int m0 = (n_img * 56 + h0) * 56;
-        ConvP pe = p;
-        pe.M = m0 + G::KPIX;                                      // rows past the chunk's pixels are padding: not stored, not counted
-        cv_epilogue<BN, LEAN, 4>(pe, acc, Stage, t, m0, 0, chunk);
-        ps ^= 1;
-    }
-}
-
 template <int WI> constexpr int cp_chunks_per_image() { return CpGeom<WI>::CPI; }
 
 }  // namespace
@@ -1252,113 +1096,96 @@ extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
     return (size_t)((M + CV_BM - 1) / CV_BM);
 }
 
-// 3x3 / stride 1 / pad 1 on a 56^2, 28^2 or 14^2 map: the patch-staged kernel, whose M tiles are chunks of whole image rows
-static int g_patch3x3_on();
-static int cp_width(int H, int W, int R, int S, int stride, int pad) {
-    return (g_patch3x3_on() && R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)) ? W : 0;
-}
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel selection. ONE function decides which kernel a launch takes and how that kernel tiles M (= how many rows the per-tile
+// statistics / BatchNorm-partial list of the launch has); dir_conv_plan_rows (what the host sizes `stats` with) and the launcher
+// both call it, and the launcher refuses a `stats_rows` that is not the plan's. No process-wide switches: what used to be
+// dir_conv_set_* is the explicit `variant` argument, and the thresholds are constants (measured: profiles/r03_conv_big_tiles.txt).
+//   variant 0 (DIR_CONV_AUTO)   the product heuristic below
+//   variant 1 / 2               128 x 128 (x 64) tiles, register-staged / LDS-DMA K loop
+//   variant 3                   patch-staged 3x3 (3x3 / stride 1 / pad 1 on square 56, 28, 14 maps only)
+//   variant 5                   256 x 256 CU tile (Cout % 256 == 0, M % 256 == 0)
+// Heuristic: the 256 x 256 CU tile from CVB_MIN_KT K-steps and CVB_MIN_TILES tiles (it loses on short K loops — the lone workgroup's
+// prologue / epilogue are exposed — and on the 7^2 layers' 98 tiles); else the patch-staged kernel for its shapes (M tiles = chunks of
+// whole image rows); else 128-row tiles: LDS-DMA from CV_DMA_MIN_KT K-steps, single-stage LDS-DMA at four workgroups per CU for
+// 128-wide launches of <= 18 steps, register-staged otherwise.
+constexpr int CVB_MIN_KT = 16, CVB_MIN_TILES = 150;
+enum { CK_UNSUPPORTED = -1, CK_TILE = 0, CK_PATCH3 = 1, CK_BIG = 2 };
+struct ConvPlan { int kind; int cpw; size_t rows; };
+
 static int cp_chunks(int W) { return W == 56 ? 28 : W == 28 ? 7 : 2; }
-// A/B switch for tools and tests (process-wide, default 1): 0 = those layers take the per-tap kernels again, 1 = patch-staged,
-// single LDS stage (four workgroups per CU), 2 = patch-staged, two stages (two per CU; measured 0.16 ms per step slower). Returns the
-// previous setting. Changes dir_conv_tile_rows accordingly — flip it only between whole forward/backward passes.
-// 3 = 1 + the 64 -> 64 channel layers on 56^2 maps run conv3x3_resident_kernel (persistent, weights resident in LDS): measured equal
-// to mode 1 in isolation (114.6 vs 108.4 us forward, 85.7 vs 87.9 us data gradient) and +1.2 % on the training step, so NOT the default.
-static int g_patch3x3 = 1;
-extern "C" int dir_conv_set_patch3x3(int mode) { const int prev = g_patch3x3; g_patch3x3 = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return prev; }
-static int g_patch3x3_on() { return g_patch3x3; }
-
-// Rows of the per-tile statistics / BatchNorm-partial list of ONE launch with this geometry (the tiling depends on the kernel
-// the launch takes): what `stats` must hold for dir_conv_fwd* / dir_conv_dgrad_bnstats.
-extern "C" size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad) {
-    if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
-    const int cw = cp_width(H, W, R, S, stride, pad);
-    if (cw) return (size_t)N * cp_chunks(cw);
-    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-    if (Ho <= 0 || Wo <= 0) return 0;
-    return dir_conv_stats_rows(N, Ho, Wo);
+static bool cp_geometry(int H, int W, int R, int S, int stride, int pad) {
+    return R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14);
 }
-
-extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
-                                  float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                  dir_stream_t stream);
-static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
-                       float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                       dir_stream_t stream);
-// A/B switch for tools and tests (process-wide, default 0 — see DESIGN.md for the measurements): 1 = the 128-wide launches that are not patch-staged take the persistent
-// ring kernel (dir_conv_ring.hip), 0 = the one-tile-per-workgroup kernels of this file. Same tiling of M either way (128 rows:
-// the `stats` list does not change). Returns the previous setting.
-// 256 x 256 CU-tile kernel: 0 = off, 1 = on for the launches conv_big_auto() picks (variant 5 of dir_conv_fwd_variant forces it), 2 = wherever
-// the geometry allows (tests). Measured per layer (profiles/r03_conv_big_tiles.txt): it wins from 16 K-steps with >= 150 tiles
-// (1024 -> 256 at 14^2: 46 -> 35 us; 3x3 256 at 14^2: 68 -> 57 us = 1040 TFLOP/s) and loses on short K loops and on the 7^2 layers' 98 tiles.
-static int g_big = 1;
-static int g_tall = 0;       // 256 x 128 single-stage form for K loops <= 18 steps (measurement switch: dir_conv_set_big(mode | 4))
-extern "C" int dir_conv_set_big(int mode) { const int prev = g_big | (g_tall << 2); g_tall = (mode >> 2) & 1; mode &= 3; g_big = mode > 2 ? 0 : mode; return prev; }
-static int g_big_min_kt = 16, g_big_min_tiles = 150;
-extern "C" int dir_conv_set_big_thresholds(int min_kt, int min_tiles) { g_big_min_kt = min_kt; g_big_min_tiles = min_tiles; return 0; }   // measurement knob
 static bool conv_big_geometry(long long M, int Cout, int RS) { return Cout % 256 == 0 && M % 256 == 0 && RS <= 9; }
-static bool conv_big_auto(long long M, int Cin, int Cout, int RS) {
-    if (!g_big || !conv_big_geometry(M, Cout, RS)) return false;
-    if (g_big == 2) return true;
-    return RS * (Cin / CV_BK) >= g_big_min_kt && (M / 256) * (Cout / 256) >= g_big_min_tiles;
+
+// (N, H, W) input map, output map (Ho, Wo); two_addends: the launch carries BOTH fused addends (the big kernel's epilogue takes one);
+// cls: one parity class of a stride-2 data gradient (always 128-row tiles)
+static ConvPlan conv_plan(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, bool two_addends,
+                          bool cls, int variant) {
+    const long long M = (long long)N * Ho * Wo;
+    const size_t rows128 = (size_t)((M + CV_BM - 1) / CV_BM);
+    if (variant == DIR_CONV_BIG)
+        return conv_big_geometry(M, Cout, R * S) ? ConvPlan{CK_BIG, 0, rows128} : ConvPlan{CK_UNSUPPORTED, 0, 0};
+    if (variant == DIR_CONV_PATCH3)
+        return (!cls && cp_geometry(H, W, R, S, stride, pad)) ? ConvPlan{CK_PATCH3, W, (size_t)N * cp_chunks(W)} : ConvPlan{CK_UNSUPPORTED, 0, 0};
+    if (variant == DIR_CONV_TILE_REG || variant == DIR_CONV_TILE_DMA) return ConvPlan{CK_TILE, 0, rows128};
+    if (variant != DIR_CONV_AUTO) return ConvPlan{CK_UNSUPPORTED, 0, 0};
+    if (!two_addends && conv_big_geometry(M, Cout, R * S) && R * S * (Cin / CV_BK) >= CVB_MIN_KT && (M / 256) * (Cout / 256) >= CVB_MIN_TILES)
+        return ConvPlan{CK_BIG, 0, rows128};
+    if (!cls && cp_geometry(H, W, R, S, stride, pad)) return ConvPlan{CK_PATCH3, W, (size_t)N * cp_chunks(W)};
+    return ConvPlan{CK_TILE, 0, rows128};
 }
-// statistics rows of ONE launch of this geometry through the product heuristic (what `stats` / the BatchNorm partial list must hold)
-extern "C" size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
-extern "C" size_t dir_conv_tile_rows_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+
+// Rows of the per-tile statistics / BatchNorm-partial list of ONE launch with this geometry through `variant` (0 = the product
+// heuristic): what `stats` must hold, and the `stats_rows` the launch entry points check. 0 = invalid geometry / variant not applicable.
+extern "C" size_t dir_conv_plan_rows(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int two_addends, int variant) {
     if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || Cin <= 0 || Cout <= 0) return 0;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
-    if (conv_big_auto((long long)N * Ho * Wo, Cin, Cout, R * S)) return dir_conv_stats_rows(N, Ho, Wo);
-    return dir_conv_tile_rows(N, H, W, R, S, stride, pad);
+    const ConvPlan pl = conv_plan(N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, two_addends != 0, false, variant);
+    return pl.kind == CK_UNSUPPORTED ? 0 : pl.rows;
 }
-static int g_ring = 0;
-static int g_ring_dbg = 0;    // measurement builds only: bit 0 = no fragment reads / MFMA, bit 1 = no LDS-DMA (mode = 1 | dbg << 4)
-extern "C" int dir_conv_set_ring(int mode) { const int prev = g_ring | (g_ring_dbg << 4); g_ring = (mode & 15) ? 1 : 0; g_ring_dbg = mode >> 4; return prev; }
+
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
-                          float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn = nullptr);
 
-extern "C" int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
-                                int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
-    return dir_conv_fwd_fused(x, w, addend, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
-}
-
-extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
+extern "C" int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int stats_rows, int N, int H, int W, int Cin,
                             int Cout, int R, int S, int stride, int pad, dir_stream_t stream) {
-    return dir_conv_fwd_add(x, w, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+    return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, DIR_CONV_AUTO, stream);
 }
 
 extern "C" int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y,
-                                  float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   dir_stream_t stream) {
-    return conv_launch(x, w, addend, nullptr, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+    return conv_launch_ex(x, w, addend, nullptr, relu_mask, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, DIR_CONV_AUTO, stream);
 }
 
-// A/B measurements and tests: the same convolution with the K-loop variant forced (0 = heuristic = dir_conv_fwd,
-// 1 = register-staged, 2 = LDS-DMA, 3 = patch-staged 3x3; 1 and 2 tile M by 128 rows: stats rows = dir_conv_stats_rows).
-extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
+// The same convolution with the kernel forced (tests and A/B measurements; DIR_EUNSUPPORTED when the geometry is not that kernel's).
+extern "C" int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout,
                                     int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
-    DIR_RETURN_IF(variant < 0 || variant > 6, DIR_EINVAL);
-    DIR_RETURN_IF(variant == 3 && !(R == 3 && S == 3 && stride == 1 && pad == 1 && H == W && (W == 56 || W == 28 || W == 14)), DIR_EUNSUPPORTED);
-    return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
+    return conv_launch_ex(x, w, nullptr, nullptr, nullptr, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, variant, stream);
 }
 
 extern "C" int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const void* addend_s2,
                                    const void* relu_mask, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                                    int pad, dir_stream_t stream) {
-    return conv_launch(x, w, addend, addend_s2, relu_mask, y, nullptr, N, H, W, Cin, Cout, R, S, 1, pad, stream);
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, nullptr, 0, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, DIR_CONV_AUTO, stream);
 }
 
 static int conv_dgrad_s2_impl(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
-                              const ConvBn* bn, float* stats, dir_stream_t stream) {
+                              const ConvBn* bn, float* stats, int stats_rows, int variant, dir_stream_t stream) {
     DIR_RETURN_IF(!dy || !wcls || !dx, DIR_EINVAL);
     // classes (a, b) in the order (0,0) (0,1) (1,0) (1,1): 1, 2, 2, 4 filter taps, packed back to back as [Cx][taps][Cy]
     static const int tap_base[4] = {0, 1, 3, 5};
     const size_t rows = dir_conv_stats_rows(N, Ho, Wo);              // partial rows per class (fused BatchNorm-backward sums)
+    DIR_RETURN_IF(stats && (size_t)stats_rows != 4 * rows, DIR_EINVAL);
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
             const uint16_t* wc = static_cast<const uint16_t*>(wcls) + (size_t)tap_base[a * 2 + b] * Cx * Cy;
             float* st = stats ? stats + (size_t)(a * 2 + b) * rows * 2 * Cx : nullptr;
-            const int rc = conv_launch_ex(dy, wc, nullptr, nullptr, nullptr, dx, st, N, Ho, Wo, Cy, Cx, 1 + a, 1 + b, 1, 0, a, b, 0, stream, bn);
+            const int rc = conv_launch_ex(dy, wc, nullptr, nullptr, nullptr, dx, st, (int)rows, N, Ho, Wo, Cy, Cx, 1 + a, 1 + b, 1, 0, a, b, variant, stream, bn);
             if (rc != DIR_OK) return rc;
         }
     return DIR_OK;
@@ -1366,54 +1193,60 @@ static int conv_dgrad_s2_impl(const void* dy, const void* wcls, void* dx, int N,
 
 extern "C" int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
                                  dir_stream_t stream) {
-    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, nullptr, nullptr, stream);
+    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, nullptr, nullptr, 0, DIR_CONV_AUTO, stream);
 }
 
 // The data gradients above with the FIRST pass of the BatchNorm backward that consumes them fused into the store loop
 // (dir_bn_bwd_partials is the rest): bn_x = the input of that BatchNorm ([N, H', W', Cout] like the result), stats =
-// [rows][2][Cout] floats, rows = dir_conv_stats_rows(N, Ho, Wo) (x 4 for the stride-2 form: one block of rows per parity
-// class). bn_gamma / bn_beta non-null: the BatchNorm is followed by a ReLU without residual; its mask is recomputed for the sums.
+// [stats_rows][2][Cout] floats, stats_rows = dir_conv_plan_rows(...) (4 x dir_conv_stats_rows(N, Ho, Wo) for the stride-2 form: one
+// block of rows per parity class). bn_gamma / bn_beta non-null: the BatchNorm is followed by a ReLU without residual; its mask is
+// recomputed for the sums.
 extern "C" int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* addend, const void* addend_s2,
                                       const void* relu_mask, void* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                                       int pad, const void* bn_x, const float* bn_gamma, const float* bn_beta,
-                                      const float* bn_mean, const float* bn_rstd, float* stats, dir_stream_t stream) {
+                                      const float* bn_mean, const float* bn_rstd, float* stats, int stats_rows, dir_stream_t stream) {
     DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
     const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, nullptr};
-    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, 0, stream, &bn);
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, DIR_CONV_AUTO, stream, &bn);
 }
 
 // The general stride-1 data gradient: dir_conv_dgrad_join (+ dir_conv_dgrad_bnstats when bn_x != NULL) with the ReLU mask given
 // either as the tensor itself (relu_mask) or as the bit mask dir_bn_fwd_train_bits / dir_bn_apply_bits emitted
-// (relu_mask_bits, [N*H*W][Cout / 8] bytes): 1/16 of the bytes for the same decision. At most one of the two.
+// (relu_mask_bits, [N*H*W][Cout / 8] bytes): 1/16 of the bytes for the same decision. At most one of the two. `variant` as in
+// dir_conv_fwd_variant (0 = the product heuristic).
 extern "C" int dir_conv_dgrad_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
                                  const void* relu_mask_bits, void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad,
                                  const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                                 const float* bn_rstd, float* stats, dir_stream_t stream) {
+                                 const float* bn_rstd, float* stats, int stats_rows, int variant, dir_stream_t stream) {
     DIR_RETURN_IF((bn_x == nullptr) != (stats == nullptr) || (bn_x && !dir_aligned16(bn_x)), DIR_EINVAL);
     DIR_RETURN_IF(bn_gamma && (!bn_x || !bn_beta || !bn_mean || !bn_rstd), DIR_EINVAL);
     const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, relu_mask_bits};
-    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, 0, stream, &bn);
+    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, 1, pad, -1, 0, variant, stream, &bn);
 }
 
 extern "C" int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
                                          const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                                         const float* bn_rstd, float* stats, dir_stream_t stream) {
+                                         const float* bn_rstd, float* stats, int stats_rows, dir_stream_t stream) {
     DIR_RETURN_IF(!bn_x || !stats || !dir_aligned16(bn_x) || (bn_gamma && (!bn_beta || !bn_mean || !bn_rstd)), DIR_EINVAL);
     const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, nullptr};
-    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, &bn, stats, stream);
+    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, &bn, stats, stats_rows, DIR_CONV_AUTO, stream);
 }
 
-static int conv_launch(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
-                       float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                       dir_stream_t stream) {
-    return conv_launch_ex(x, w, addend, addend_s2, relu_mask, y, stats, N, H, W, Cin, Cout, R, S, stride, pad, -1, 0, 0, stream);
+// The stride-2 3x3 data gradient with everything explicit (tests: the parity-class launches through a forced kernel).
+extern "C" int dir_conv_dgrad_s2_ex(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                                    const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                    const float* bn_rstd, float* stats, int stats_rows, int variant, dir_stream_t stream) {
+    DIR_RETURN_IF((bn_x == nullptr) != (stats == nullptr) || (bn_x && !dir_aligned16(bn_x)), DIR_EINVAL);
+    DIR_RETURN_IF(bn_gamma && (!bn_x || !bn_beta || !bn_mean || !bn_rstd), DIR_EINVAL);
+    const ConvBn bn{bn_x, bn_gamma, bn_beta, bn_mean, bn_rstd, nullptr};
+    return conv_dgrad_s2_impl(dy, wcls, dx, N, Ho, Wo, Cy, Cx, bn_x ? &bn : nullptr, stats, stats_rows, variant, stream);
 }
 
 // cls_a >= 0: parity class (cls_a, cls_b) of a stride-2 data gradient: x = dY [N, H, W, Cin], kernel (1 + a) x (1 + b)
 // anchored top-left (zero beyond the bottom / right edge), output grid H x W stored at pixels (2 i + a, 2 j + b) of
 // y [N, 2 H, 2 W, Cout]
 static int conv_launch_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask, void* y,
-                          float* stats, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int cls_a, int cls_b, int variant, dir_stream_t stream, const ConvBn* bn) {
     DIR_RETURN_IF(!x || !w || !y, DIR_EINVAL);
     const bool fwd_stats = stats && !(bn && bn->x);                              // forward statistics are of the conv result alone
@@ -1432,6 +1265,10 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     DIR_RETURN_IF(addend_s2 && ((Ho | Wo) & 1), DIR_EUNSUPPORTED);
     const long long M = (long long)N * Ho * Wo;
     DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);   // 32-bit byte offsets into x
+    // which kernel, and how it tiles M: the caller's statistics list must have exactly the rows that kernel writes
+    const ConvPlan plan = conv_plan(N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, addend && addend_s2, cls, variant);
+    DIR_RETURN_IF(plan.kind == CK_UNSUPPORTED, (variant < 0 || variant > DIR_CONV_BIG || variant == 4) ? DIR_EINVAL : DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(stats && (size_t)stats_rows != plan.rows, DIR_EINVAL);
     ConvP p;
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
     p.stats = stats;
@@ -1453,94 +1290,45 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     p.ntn = wide ? Cout / 128 : Cout / 64;
     p.nblocks = mtiles * p.ntn;
     hipStream_t s = dir_s(stream);
-    // K-loop variant. 2 = LDS-DMA (two 32/24 KB stages, no staging registers): loops of >= CV_DMA_MIN_KT steps, where the LDS
-    // pipe bounds the register-staged loop. 1 = register-staged: LDS stages 2 (64 KB, 2 workgroups per CU) for long K loops,
-    // 1 (43 KB, 3 per CU, one extra barrier) when the loop is short and the layer is bound by memory latency; prefetch
-    // distance 2 K-tiles once the loop is long enough to use them. `variant` 0 = this heuristic (the product path).
     const int tile_n = wide ? 128 : 64;
     const int stage = CV_BM * (tile_n * 2 + 16) + 4 * 2 * tile_n * 4;      // epilogue staging + column partials
-    // (takes precedence over the patch-staged 3x3 kernel; dir_conv_tile_rows_ex sizes the caller's statistics buffer with the same rule)
-    // variant 6 / g_tall: the 256 x 128 single-stage form (8 wavefronts, two workgroups per CU) for short K loops
-    const bool tall = (variant == 6 && M % 256 == 0 && Cout % 128 == 0 && R * S <= 9) ||
-                      (variant == 0 && g_tall && M % 256 == 0 && Cout % 128 == 0 && R * S <= 9 && p.KT <= 18 && !(p.addend && p.addend2) && !cp_width(H, W, R, S, stride, pad));
-    const bool big = tall || (variant == 5 && conv_big_geometry(M, Cout, R * S)) || (variant == 0 && conv_big_auto(M, Cin, Cout, R * S) && !(p.addend && p.addend2));
-    const int cpw = (cls || big || variant == 1 || variant == 2 || variant == 4 || variant == 5 || variant == 6) ? 0 : (variant == 3 ? W : cp_width(H, W, R, S, stride, pad));
-    if (cpw) {
-        // patch-staged 3x3: M tiles = chunks of whole image rows
+    if (plan.kind == CK_PATCH3) {
+        // patch-staged 3x3: M tiles = chunks of whole image rows; one LDS stage (126 registers, 40 KB: four workgroups per CU)
+        const int cpw = plan.cpw;
         p.nblocks = N * cp_chunks(cpw) * p.ntn;
-        if (cpw == 56 && Cin == 64 && Cout == 64 && g_patch3x3 == 3 && variant != 3 && !(p.addend && p.addend2)) {
-            // stage 1's conv2 (and its data gradient): persistent workgroups with all nine taps of the weights resident in LDS
-            const int nchunks = N * cp_chunks(56);
-            static int cus = 0;
-            if (!cus) {
-                int dev = 0; hipDeviceProp_t prop;
-                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            }
-            const int grid = nchunks < cus ? nchunks : cus;
-            constexpr int lds_res = 9 * 64 * CV_ROWB + 2 * 256 * CV_ROWB + CV_BM * (64 * 2 + 16) + 4 * 2 * 64 * 4;     // 159 744
-            static bool once_res = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_res),
-                                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_res), true);
-            (void)once_res;
-            const bool lean3 = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
-            if (lean3) hipLaunchKernelGGL(conv3x3_resident_kernel<true>, dim3(grid), dim3(DIR_TPB), lds_res, s, p, nchunks);
-            else hipLaunchKernelGGL(conv3x3_resident_kernel<false>, dim3(grid), dim3(DIR_TPB), lds_res, s, p, nchunks);
-            DIR_LAUNCH_CHECK();
-            return DIR_OK;
-        }
-        const int nst = g_patch3x3 == 2 ? 2 : 1;                        // default: single stage, four workgroups per CU
-        const int npatch = (nst == 2 && p.cpk > 1) ? 2 : 1;
         const int prows = cpw == 56 ? 256 : cpw == 28 ? 192 : 144;
-        const int loop3 = npatch * prows * CV_ROWB + nst * tile_n * CV_ROWB;
+        const int loop3 = prows * CV_ROWB + tile_n * CV_ROWB;
         const int lds3 = loop3 > stage ? loop3 : stage;
-#define CP_LAUNCH(W_, BN_)                                                                                                    \
-        {                                                                                                                         \
-            static bool once_cp = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<W_, BN_, 2>),      \
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 98304), true);            \
-            (void)once_cp;                                                                                                        \
-            if (nst == 1) hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_, 1>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);      \
-            else hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_, 2>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p);               \
-        }
-        if (cpw == 56) { if (wide) CP_LAUNCH(56, 128) else CP_LAUNCH(56, 64) }
-        else if (cpw == 28) { if (wide) CP_LAUNCH(28, 128) else CP_LAUNCH(28, 64) }
-        else { if (wide) CP_LAUNCH(14, 128) else CP_LAUNCH(14, 64) }
+#define CP_LAUNCH(W_, BN_) hipLaunchKernelGGL((conv3x3_patch_kernel<W_, BN_, 1>), dim3(p.nblocks), dim3(DIR_TPB), lds3, s, p)
+        if (cpw == 56) { if (wide) CP_LAUNCH(56, 128); else CP_LAUNCH(56, 64); }
+        else if (cpw == 28) { if (wide) CP_LAUNCH(28, 128); else CP_LAUNCH(28, 64); }
+        else { if (wide) CP_LAUNCH(14, 128); else CP_LAUNCH(14, 64); }
 #undef CP_LAUNCH
         DIR_LAUNCH_CHECK();
         return DIR_OK;
     }
-    DIR_RETURN_IF((variant == 5 || variant == 6) && !big, DIR_EUNSUPPORTED);
-    if (big) {
+    if (plan.kind == CK_BIG) {
         // 256 x 256 CU tile on 16 wavefronts (half the LDS-DMA pieces per FLOP)
+        using G = CvbGeom<256, 256, 2>;
         const bool leanb = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
-#define CVB_GO(TM_, TN_, NST_)                                                                                                            \
-        {                                                                                                                                 \
-            using G = CvbGeom<TM_, TN_, NST_>;                                                                                            \
-            static bool once_big = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<TM_, TN_, NST_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), \
-                                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<TM_, TN_, NST_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), true); \
-            (void)once_big;                                                                                                               \
-            const int ntn2 = Cout / TN_, nb2 = (int)(M / TM_) * ntn2;                                                                     \
-            if (leanb) hipLaunchKernelGGL((conv_igemm_big_kernel<TM_, TN_, NST_, true>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2); \
-            else hipLaunchKernelGGL((conv_igemm_big_kernel<TM_, TN_, NST_, false>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2); \
-        }
-        if (tall) CVB_GO(256, 128, 1) else CVB_GO(256, 256, 2)
-#undef CVB_GO
+        DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<256, 256, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_big_kernel<256, 256, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        const int ntn2 = Cout / 256, nb2 = (int)(M / 256) * ntn2;
+        if (leanb) hipLaunchKernelGGL((conv_igemm_big_kernel<256, 256, 2, true>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2);
+        else hipLaunchKernelGGL((conv_igemm_big_kernel<256, 256, 2, false>), dim3(nb2), dim3(G::THREADS), G::LDS, s, p, ntn2, nb2);
         DIR_LAUNCH_CHECK();
         return DIR_OK;
     }
-    if (variant == 4 || (variant == 0 && g_ring)) {
-        // persistent ring kernel (8 wavefronts, loader / storer roles, ring of LDS-DMA stages across tile boundaries)
-        if (conv_ring_takes(p)) {
-            const int rc = conv_ring_launch(p, g_ring_dbg, s);
-            return rc == 0 ? DIR_OK : rc;
-        }
-        DIR_RETURN_IF(variant == 4, DIR_EUNSUPPORTED);
-    }
-    const bool dma = variant == 2 || (variant == 0 && p.KT >= CV_DMA_MIN_KT);
+    // ---- 128-row tiles. K-loop form: 2 = LDS-DMA (two 32/24 KB stages, no staging registers): loops of >= CV_DMA_MIN_KT steps, where
+    // the LDS pipe bounds the register-staged loop. 1 = register-staged: LDS stages 2 (64 KB, 2 workgroups per CU) for long K loops,
+    // 1 (43 KB, 3 per CU, one extra barrier) when the loop is short and the layer is bound by memory latency; prefetch distance 2
+    // K-tiles once the loop is long enough to use them.
+    const bool dma = variant == DIR_CONV_TILE_DMA || (variant == DIR_CONV_AUTO && p.KT >= CV_DMA_MIN_KT);
     if (dma) {
         const int loop2 = 2 * (CV_BM * CV_ROWB + tile_n * CV_ROWB);
         const int lds2 = loop2 > stage ? loop2 : stage;
-        static bool once_dma = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
-                                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
-        (void)once_dma;
+        DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         if (wide) hipLaunchKernelGGL((conv_igemm_dma_kernel<128>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
         else hipLaunchKernelGGL((conv_igemm_dma_kernel<64>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
         DIR_LAUNCH_CHECK();
@@ -1551,9 +1339,8 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     if (pf == 2) p.nbuf = 2;                                        // the two-tile prefetch is written for two LDS stages
     const int loop2 = p.nbuf * (CV_BM * CV_ROWB + tile_n * CV_ROWB);
     const int lds2 = loop2 > stage ? loop2 : stage;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
-    (void)once;
+    DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
 #define CV_LAUNCH(BN_, PF_, NB_) hipLaunchKernelGGL((conv_igemm_kernel<BN_, PF_, NB_>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p)
     // lean = no fused operand (the plain forward): the single-stage kernel then fits four workgroups per CU
     const bool lean = !p.addend && !p.addend2 && !p.mask && !p.mask_bits && !p.bnx && !p.o2;
@@ -1561,7 +1348,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     // of LDS) instead of three — throughput of these launches follows the resident workgroups (profiles/r02_conv_occupancy_sensitivity.txt;
     // A/B per train step -0.8 ms, per epoch-tail forward -0.7 ms). The 64-wide register-staged kernel already runs four per CU
     // (the DMA form measured slower there).
-    const bool single = wide && p.nbuf == 1 && pf == 1 && variant == 0;
+    const bool single = wide && p.nbuf == 1 && pf == 1 && variant == DIR_CONV_AUTO;
     if (single && lean) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 1, true>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
     else if (single) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 1, false>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);
     else if (!wide && lean && p.nbuf == 1 && pf == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, 1, 1, true>), dim3(p.nblocks), dim3(DIR_TPB), lds2, s, p);

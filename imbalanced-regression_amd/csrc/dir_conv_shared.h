@@ -1,5 +1,4 @@
-// Shared pieces of the MFMA implicit-GEMM convolution kernels (dir_conv.hip: one tile per workgroup; dir_conv_ring.hip: the
-// persistent 8-wavefront ring kernel): launch parameters, tile constants, bf16 packing, accumulator staging, inline-asm LDS-DMA.
+// Shared pieces of the MFMA implicit-GEMM convolution kernels (dir_conv.hip): launch parameters, tile constants, bf16 packing, accumulator staging, inline-asm LDS-DMA.
 #pragma once
 #include "dir_common.h"
 
@@ -86,8 +85,3 @@ __device__ __forceinline__ void cp_dma16(cp_u32x4 rs, uint32_t lds_addr, int vof
                  : "=&s"(keep) : "s"(lds_addr), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
 }
 __device__ __forceinline__ void cp_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-
-// dir_conv_ring.hip: persistent ring kernel (returns 0 when the launch was made, < 0 = this geometry is not taken by it)
-int conv_ring_launch(const ConvP& p, int force, hipStream_t s);
-bool conv_ring_takes(const ConvP& p);

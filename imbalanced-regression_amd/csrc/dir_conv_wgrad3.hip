@@ -228,17 +228,6 @@ conv_wgrad3_kernel(Wg3P p) {
     }
 }
 
-// Probe of the transposing LDS read (tests): LDS holds the uint16 ramp 0, 1, 2, ...; lane l reads at byte address addr[l]
-__global__ void __launch_bounds__(64) w3_tr_probe_kernel(const int* __restrict__ addr, uint16_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint16_t ramp[8192];
-    for (int i = threadIdx.x; i < 8192; i += 64) ramp[i] = (uint16_t)i;
-    __syncthreads();
-    const w3_bf16x4 v = w3_tr(reinterpret_cast<const unsigned char*>(ramp) + addr[threadIdx.x]);
-    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)(bits >> (16 * j));
-}
-
 struct W3Plan { int nco, nci, nsplit, units, ups; size_t ws_bytes; };
 
 bool w3_shape_ok(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
@@ -268,8 +257,7 @@ template <int WI>
 void w3_launch(const Wg3P& p, hipStream_t s) {
     using G = W3Geom<WI>;
     constexpr int lds = 2 * G::STAGE > W3_RED_BYTES ? 2 * G::STAGE : W3_RED_BYTES;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel<WI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
-    (void)once;
+    DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel<WI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL((conv_wgrad3_kernel<WI>), dim3(p.nco * p.nci * p.nsplit), dim3(W3_TPB), lds, s, p);
 }
 
@@ -301,11 +289,4 @@ extern "C" int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N
     else w3_launch<7>(p, s);
     DIR_LAUNCH_CHECK();
     return dir_conv_wgrad_reduce_splits(p.part, pl.nsplit, (size_t)Cout * 9 * Cin, dw, stream);
-}
-
-extern "C" int dir_probe_tr16(const int* addr_bytes, void* out, dir_stream_t stream) {
-    DIR_RETURN_IF(!addr_bytes || !out, DIR_EINVAL);
-    hipLaunchKernelGGL(w3_tr_probe_kernel, dim3(1), dim3(64), 0, dir_s(stream), addr_bytes, static_cast<uint16_t*>(out));
-    DIR_LAUNCH_CHECK();
-    return DIR_OK;
 }

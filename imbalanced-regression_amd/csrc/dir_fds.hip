@@ -805,9 +805,8 @@ static int fds_calibrate_lds_launch(float* x, const int32_t* bins, long long B, 
     const size_t lds = (size_t)3 * nb * tw * 4;
 #define FDS_LDS_GO(TW_)                                                                                                        \
     {                                                                                                                          \
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_lds_kernel<TW_>),            \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);          \
-        (void)once;                                                                                                            \
+        DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_lds_kernel<TW_>),            \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
         hipLaunchKernelGGL(fds_calibrate_lds_kernel<TW_>, dim3(nct, ny), dim3(FDS_LDS_TPB), lds, s, x, bins, B, C, nb, m1, scale, m2, rows_per_wg); \
     }
     if (tw == 128) FDS_LDS_GO(128) else if (tw == 64) FDS_LDS_GO(64) else if (tw == 32) FDS_LDS_GO(32) else FDS_LDS_GO(16)
@@ -899,9 +898,8 @@ static int fds_nchw_launch(bool bwd, const float* x, float* y, const int32_t* bi
     long long want = (npix / 4 + FDS_LDS_TPB - 1) / FDS_LDS_TPB;
     int grid = (int)(want < 256 ? (want < 1 ? 1 : want) : 256);
     if (lds <= 64 * 1024 && want > 256) grid = (int)(want < 512 ? want : 512);
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (bwd) hipLaunchKernelGGL(fds_calibrate_nchw_kernel<true>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
     else hipLaunchKernelGGL(fds_calibrate_nchw_kernel<false>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
     DIR_LAUNCH_CHECK();

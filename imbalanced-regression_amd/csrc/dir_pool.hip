@@ -373,9 +373,6 @@ bn_relu_maxpool_bwd_apply2x2_kernel(const uint16_t* __restrict__ dy, const uint8
 }
 }  // namespace
 
-static int g_stem_tail_mode = 3;    // bit 0: backward reduction streams the forward's xmax; bit 1: 2 x 2-block apply pass
-extern "C" int dir_stem_tail_set_mode(int mode) { const int prev = g_stem_tail_mode; g_stem_tail_mode = mode & 3; return prev; }
-
 extern "C" int dir_bn_relu_maxpool_fwd_xmax(const void* x, const float* coef, void* y, void* argmax, void* xmax, int N, int H, int W, int C,
                                             dir_stream_t stream) {
     DIR_RETURN_IF(!x || !coef || !y || !argmax || N <= 0 || H <= 0 || W <= 0 || C <= 0, DIR_EINVAL);
@@ -415,11 +412,11 @@ extern "C" int dir_bn_relu_maxpool_bwd_xmax(const void* dy, const void* argmax, 
     hipStream_t s = dir_s(stream);
     hipLaunchKernelGGL(bn_relu_maxpool_bwd_partial_kernel, dim3(SP_BLOCKS), dim3(DIR_TPB), 2 * DIR_TPB * 8 * sizeof(float), s,
                        static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x),
-                       (g_stem_tail_mode & 1) ? static_cast<const uint16_t*>(xmax) : nullptr, partial, N, H, W, C, Ho, Wo);
+                       static_cast<const uint16_t*>(xmax), partial, N, H, W, C, Ho, Wo);
     DIR_LAUNCH_CHECK();
     const int rc = dir_bn_bwd_finalize(partial, SP_BLOCKS, (int64_t)N * H * W, C, gamma, save_mean, save_rstd, dgamma, dbeta, coef, stream);
     if (rc != DIR_OK) return rc;
-    if (g_stem_tail_mode & 2) {
+    if (xmax) {
         const long long blocks = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply2x2_kernel, dim3((unsigned)((blocks + DIR_TPB - 1) / DIR_TPB)), dim3(DIR_TPB), 0, s,
                            static_cast<const uint16_t*>(dy), static_cast<const uint8_t*>(argmax), static_cast<const uint16_t*>(x), coef,

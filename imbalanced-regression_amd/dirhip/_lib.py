@@ -55,51 +55,38 @@ SIGNATURES = {
     "dir_bn_bwd_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_bn_bwd_join": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_int] + [c_void_p] * 11 + [c_size_t, c_void_p]),
-    "dir_conv_dgrad_ex": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p] * 7),
+    "dir_conv_dgrad_ex": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "dir_bn_fwd_train_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_bn_apply_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
-    "dir_conv_dgrad_bnstats": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p] * 7),
-    "dir_conv_dgrad_s2_bnstats": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 7),
+    "dir_conv_dgrad_bnstats": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p] * 6 + [c_int, c_void_p]),
+    "dir_conv_dgrad_s2_bnstats": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 6 + [c_int, c_void_p]),
+    "dir_conv_dgrad_s2_ex": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "dir_conv_plan_rows": (c_size_t, [c_int] * 11),
     "dir_bn_prepare_train": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_bn_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
-    "dir_conv_tile_rows": (c_size_t, [c_int] * 7),
-    "dir_conv_tile_rows_ex": (c_size_t, [c_int] * 9),
-    "dir_conv_set_patch3x3": (c_int, [c_int]),
-    "dir_conv_set_ring": (c_int, [c_int]),
-    "dir_conv_set_big": (c_int, [c_int]),
-    "dir_conv_set_big_thresholds": (c_int, [c_int, c_int]),
     "dir_adam_step": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_longlong, c_void_p]),
-    "dir_bn_set_fused_finalize": (c_int, [c_int]),
-    "dir_bn_set_grid_cap": (c_int, [c_int]),
-    "dir_bn_set_apply_chunk": (c_int, [c_int]),
     "dir_conv_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_conv_prep_weights_batched": (c_int, [c_void_p, c_int, c_void_p]),
     "dir_conv_prep_weights_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dir_conv_dgrad_s2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dir_conv_fwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, c_int, c_int, c_void_p]),
-    "dir_conv_fwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_int, c_int, c_void_p]),
+    "dir_conv_fwd_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "dir_stem_conv_stats_rows": (c_size_t, [c_int, c_int]),
     "dir_stem_conv_prep_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dir_stem_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dir_stem_conv_wgrad_workspace": (c_size_t, [c_int, c_int]),
     "dir_stem_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_dgrad_join": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
-    "dir_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                             c_int, c_int, c_void_p]),
-    "dir_conv_fwd_variant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "dir_conv_fwd": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dir_conv_fwd_variant": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     "dir_conv_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad3x3_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad_reduce_splits": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
-    "dir_probe_l2_read": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
-    "dir_probe_tr16": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dir_augment_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -107,7 +94,6 @@ SIGNATURES = {
     "dir_bn_relu_maxpool_fwd_xmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_bn_relu_maxpool_bwd_xmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dir_stem_tail_set_mode": (c_int, [c_int]),
     "dir_bn_relu_maxpool_bwd_workspace": (c_size_t, [c_int]),
     "dir_bn_relu_maxpool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -131,15 +117,12 @@ SIGNATURES = {
     "dir_tail_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9),
     "dir_tail_bwd_workspace": (c_size_t, [c_int, c_int]),
     "dir_tail_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dir_probe_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dir_probe_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dir_probe_stream_write": (c_int, [c_void_p, c_size_t, c_void_p]),
-    "dir_probe_mfma_bf16": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dir_probe_mfma_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
+ABI_VERSION = 2
 DIR_F32, DIR_BF16 = 0, 1
+CONV_AUTO, CONV_TILE_REG, CONV_TILE_DMA, CONV_PATCH3, CONV_BIG = 0, 1, 2, 3, 5      # DIR_CONV_* of include/dir_hip.h
 FLAG_HAS_LO, FLAG_HAS_HI, FLAG_NONINTEGER, FLAG_NAN = 1, 2, 4, 8
 FACTOR_ZERO, FACTOR_MOMENTUM, FACTOR_COUNT = 0, 1, 2
 LOSS_KINDS = {"mse": 0, "l1": 1, "focal_mse": 2, "focal_l1": 3, "huber": 4}
@@ -165,7 +148,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError = ABI mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if handle.dir_abi_version() != 1:
+        if handle.dir_abi_version() != ABI_VERSION:
             raise DirHipError(f"ABI version mismatch: {handle.dir_abi_version()}")
         _lib = handle
     return _lib

@@ -40,7 +40,9 @@ def _bn_link_args(link):
 
 
 def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_mask=None, addend_s2=None, bn_link=None,
-                 relu_bits=None):
+                 relu_bits=None, variant=L.CONV_AUTO):
+    """``variant``: ``L.CONV_*`` (``DIR_CONV_*`` of the C-ABI) — the kernel of THIS launch; 0 = the product heuristic. The statistics /
+    BatchNorm-partial lists are sized by ``dir_conv_plan_rows`` for that same kernel and the launch checks the number."""
     if not x.is_cuda:
         raise L.DirHipError(f"conv2d_igemm: input on {x.device}; MFMA convolution runs only on the GPU (no CPU fallback)")
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
@@ -54,9 +56,12 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
     ho = (h + 2 * padding - r) // stride + 1
     wo = (wd + 2 * padding - s) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    stats = None
+    stats, rows = None, 0
+    if want_stats or bn_link is not None:
+        rows = L.lib().dir_conv_plan_rows(n, h, wd, cin, cout, r, s, stride, padding, int(addend is not None and addend_s2 is not None), variant)
+        if rows == 0:
+            raise L.DirHipError(f"conv2d_igemm: kernel variant {variant} does not take this geometry ({tuple(x.shape)} * {tuple(w.shape)}, stride {stride})")
     if want_stats:
-        rows = L.lib().dir_conv_tile_rows_ex(n, h, wd, cin, cout, r, s, stride, padding)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     if addend is not None:
         assert addend.shape == y.shape and addend.dtype == torch.bfloat16 and not want_stats
@@ -78,23 +83,32 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
         part, bn_args = None, (None, None, None, None, None)
         if bn_link is not None:
             assert bn_link.x.shape == y.shape and bn_link.x.dtype == torch.bfloat16
-            rows = L.lib().dir_conv_tile_rows_ex(n, h, wd, cin, cout, r, s, 1, padding)
             part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
             bn_args = _bn_link_args(bn_link)
         if relu_bits is not None:
             assert relu_bits.dtype == torch.uint8 and relu_bits.numel() * 8 == y.numel()
         L.check(L.lib().dir_conv_dgrad_ex(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(relu_bits), L.ptr(y),
-                                          n, h, wd, cin, cout, r, s, padding, *bn_args, L.ptr(part), L.stream_ptr(x.device)),
+                                          n, h, wd, cin, cout, r, s, padding, *bn_args, L.ptr(part), rows if part is not None else 0, variant,
+                                          L.stream_ptr(x.device)),
                 "dir_conv_dgrad_ex")
         if bn_link is not None:
             bn_link.partial = part
             bn_link.note_dout(y)
         return y
-    if addend_s2 is not None:
+    if addend_s2 is not None and variant == L.CONV_AUTO:
         L.check(L.lib().dir_conv_dgrad_join(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(y), n, h, wd,
                                             cin, cout, r, s, padding, L.stream_ptr(x.device)), "dir_conv_dgrad_join")
         return y
-    L.check(L.lib().dir_conv_fwd_fused(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(relu_mask), L.ptr(y), L.ptr(stats), n, h, wd,
+    if variant != L.CONV_AUTO:
+        if addend is None and relu_mask is None and addend_s2 is None:
+            L.check(L.lib().dir_conv_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), rows if want_stats else 0, n, h, wd, cin, cout, r, s,
+                                                 stride, padding, variant, L.stream_ptr(x.device)), "dir_conv_fwd_variant")
+        else:
+            assert stride == 1 and not want_stats
+            L.check(L.lib().dir_conv_dgrad_ex(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), None, L.ptr(y), n, h, wd, cin, cout,
+                                              r, s, padding, None, None, None, None, None, None, 0, variant, L.stream_ptr(x.device)), "dir_conv_dgrad_ex")
+        return (y, stats) if want_stats else y
+    L.check(L.lib().dir_conv_fwd_fused(L.ptr(x), L.ptr(w), L.ptr(addend), L.ptr(relu_mask), L.ptr(y), L.ptr(stats), rows if want_stats else 0, n, h, wd,
                                        cin, cout, r, s, stride, padding, L.stream_ptr(x.device)), "dir_conv_fwd")
     return (y, stats) if want_stats else y
 
@@ -270,7 +284,7 @@ class _ConvFn(torch.autograd.Function):
             if link is not None and dalias is None:
                 part = torch.empty((4 * L.lib().dir_conv_stats_rows(n_, h_ // 2, w_ // 2), 2, cin_), dtype=torch.float32, device=x.device)
                 L.check(L.lib().dir_conv_dgrad_s2_bnstats(L.ptr(dy), L.ptr(w16_rot), L.ptr(dx), n_, h_ // 2, w_ // 2, dy.shape[1], cin_,
-                                                          *_bn_link_args(link), L.ptr(part), L.stream_ptr(x.device)),
+                                                          *_bn_link_args(link), L.ptr(part), part.shape[0], L.stream_ptr(x.device)),
                         "dir_conv_dgrad_s2_bnstats")
                 link.partial = part
                 link.note_dout(dx)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIR_ABI_VERSION 1
+#define DIR_ABI_VERSION 2
 
 #define DIR_OK            0
 #define DIR_EINVAL       (-1)   /* bad argument (null pointer, non-positive size, ks even, ...) */
@@ -212,16 +212,6 @@ int dir_lds_weights(const double* labels, int64_t n, int max_target, int reweigh
  * workspace: >= dir_bn_workspace(dtype, M, C) bytes (0 = unsupported shape), 256-byte aligned.
  */
 size_t dir_bn_workspace(int dtype, int64_t M, int C);
-/* A/B switch for tools and tests (process-wide, default 0 — measured neutral): 1 = the training-mode forward and the backward compute their per-channel
- * coefficients INSIDE the apply pass (fold of the partial list + apply: no finalize launch), 0 = fold + finalize + apply (round 2).
- * Returns the previous setting. */
-int dir_bn_set_fused_finalize(int mode);
-/* Measurement knob (tools): workgroups per BatchNorm streaming launch (default 768 = 3 per CU); returns the previous value. */
-int dir_bn_set_grid_cap(int cap);
-/* Row walk of the element-wise BatchNorm passes (forward apply, backward apply, join apply). 0 = persistent sweep (<= grid-cap
- * workgroups, each striding over the whole tensor); iters > 0 = one short-lived workgroup per `iters` consecutive 4 KB row groups,
- * launched in address order. Same arithmetic per element: results are bit-identical. Returns the previous value. */
-int dir_bn_set_apply_chunk(int iters);
 int dir_bn_fwd_train(const void* x, const void* residual, void* y, int dtype, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      double momentum, double eps, int relu, float* save_mean, float* save_rstd,
@@ -293,31 +283,20 @@ int dir_bn_apply(const void* x, const void* residual, const float* residual_coef
  * rotated, in/out-transposed weights.
  */
 size_t dir_conv_stats_rows(int N, int Ho, int Wo);
-/* Rows of that list for ONE launch of this geometry: dir_conv_stats_rows(N, Ho, Wo) for the kernels that tile M by 128 rows;
- * N x (chunks of whole image rows per image) for the 3x3 / stride-1 / pad-1 layers on 56^2, 28^2, 14^2 maps, which run the
- * patch-staged kernel (the input patch of a chunk is staged in LDS once per 64-channel block and all nine taps read it there,
- * instead of nine shifted fetches of the same pixels).  Use this to size `stats` of dir_conv_fwd* / dir_conv_dgrad_bnstats. */
-size_t dir_conv_tile_rows(int N, int H, int W, int R, int S, int stride, int pad);
-/* The same with the channel counts: the 256 x 256 CU-tile kernel (dir_conv_set_big) takes some launches the patch-staged kernel would
- * otherwise take, with one statistics row per 128 output pixels. This is the function the host side sizes `stats` with. */
-size_t dir_conv_tile_rows_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
-/* A/B switch for tools and tests (process-wide, default 1): 0 = the 3x3 / stride-1 layers take the per-tap kernels again (and
- * dir_conv_tile_rows answers accordingly), 1 = patch-staged with one LDS stage (four workgroups per CU), 2 = patch-staged with
- * two stages (two per CU), 3 (round-3 experiment, not faster) = 1, and the 64 -> 64 channel layers on 56^2 maps (conv2 of stage 1 and its
- * data gradient) run persistent workgroups with all nine taps of the weights resident in LDS (conv3x3_resident_kernel: no weight
- * traffic, no per-tap barrier, the next patch's DMA issued ahead of the stores; bit-identical results and statistics).
- * Returns the previous setting; flip only between whole passes. */
-int dir_conv_set_patch3x3(int mode);
-/* A/B switch for tools and tests (process-wide, default 0): 1 = launches with Cout % 128 == 0 that are not patch-staged run the
- * persistent ring kernel (csrc/dir_conv_ring.hip: 8 wavefronts per CU with loader / storer roles, LDS-DMA ring across tile
- * boundaries), 0 = the one-tile-per-workgroup kernels.  Same results bit for bit, same `stats` rows.  Returns the previous setting. */
-int dir_conv_set_ring(int mode);
-/* 256 x 256 CU-tile kernel (one 1024-thread workgroup, 16 wavefronts with 64 x 64 wave tiles sharing one 64 KB K-step stage: half the
- * LDS-DMA pieces per FLOP of the 128 x 128 tiles; same epilogues, results bit-identical). 0 = never, 1 (default) = for launches with >= 16 K-steps
- * and >= 150 tiles, 2 = whenever the geometry allows (tests); + 4 = K loops of <= 18 steps take the 256 x 128 single-stage form (measurement). Process-wide; returns the previous mode. */
-int dir_conv_set_big(int mode);
-/* Measurement knob: the two thresholds of mode 1 (defaults 16 K-steps, 150 tiles). */
-int dir_conv_set_big_thresholds(int min_kt, int min_tiles);
+/* Kernel of a launch, chosen per launch (there is no process-wide switch): DIR_CONV_AUTO = the product heuristic — the 256 x 256
+ * CU-tile kernel (one 1024-thread workgroup, 16 wavefronts with 64 x 64 wave tiles sharing one 64 KB K-step stage) for launches
+ * with >= 16 K-steps and >= 150 tiles and at most one fused addend; the patch-staged kernel for 3x3 / stride-1 / pad-1 layers on
+ * 56^2, 28^2, 14^2 maps (the input patch of a chunk of whole image rows is staged in LDS once per 64-channel block and all nine
+ * taps read it there); 128-row tiles otherwise.  The other values force one kernel (tests, A/B measurements): the launch returns
+ * DIR_EUNSUPPORTED when the geometry is not that kernel's. */
+enum { DIR_CONV_AUTO = 0, DIR_CONV_TILE_REG = 1 /* 128-row tiles, register-staged K loop */, DIR_CONV_TILE_DMA = 2 /* 128-row tiles,
+       LDS-DMA K loop */, DIR_CONV_PATCH3 = 3 /* patch-staged 3x3 */, DIR_CONV_BIG = 5 /* 256 x 256 CU tile: Cout % 256 == 0, M % 256 == 0 */ };
+/* Rows of the `stats` list of ONE launch of this geometry through `variant`: the kernels tile M differently (128 output pixels per
+ * row for the tile and CU-tile kernels, one row per chunk of whole image rows for the patch-staged kernel), and which kernel AUTO
+ * picks also depends on whether the launch carries BOTH fused addends (two_addends).  The host sizes `stats` with this function and
+ * passes the same number as `stats_rows` to the launch, which re-derives it from the kernel it is about to run and returns
+ * DIR_EINVAL on a mismatch (a list sized for another tiling would be overrun or half-filled).  0 = invalid / not applicable. */
+size_t dir_conv_plan_rows(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int two_addends, int variant);
 /* float32 master weight [Cout][R][S][Cin] -> bf16 copy (same layout) and, if w16_rot != NULL, the data-gradient
  * weight [Cin][R][S][Cout] with the taps rotated by 180 degrees.  One launch per layer per optimizer step. */
 int dir_conv_prep_weights(const float* w, int Cout, int R, int S, int Cin, void* w16, void* w16_rot,
@@ -343,20 +322,17 @@ int dir_conv_prep_weights_ex(const float* w, int Cout, int R, int S, int Cin, vo
  * sum over the class's taps of dY[n, i+dr, j+ds, :] * W.  Every dx element is written exactly once: no zero fill, no
  * atomics.  dy [N, Ho, Wo, Cy] bf16, dx [N, 2 Ho, 2 Wo, Cx] bf16, wcls from dir_conv_prep_weights_ex(rot_mode = 1). */
 int dir_conv_dgrad_s2(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx, dir_stream_t stream);
-int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin,
+int dir_conv_fwd(const void* x, const void* w, void* y, float* stats, int stats_rows, int N, int H, int W, int Cin,
                  int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
-/* y = bf16(bf16(conv(x, w)) + addend): the gradient accumulation autograd would run as a separate add kernel at a
- * fan-out (block input feeding conv1 and the identity shortcut), fused into the data-gradient convolution's store
- * loop.  addend [N, Ho, Wo, Cout] bf16; stats must be NULL. */
-int dir_conv_fwd_add(const void* x, const void* w, const void* addend, void* y, float* stats, int N, int H,
-                     int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
-/* ... and additionally zeroed where !(relu_mask > 0): y = relu'(relu_mask) * bf16(bf16(conv(x, w)) + addend).  With x = dY
+/* y = relu'(relu_mask) * bf16(bf16(conv(x, w)) + addend): the gradient accumulation autograd would run as a separate add kernel at
+ * a fan-out (block input feeding conv1 and the identity shortcut) and the ReLU backward, fused into the data-gradient convolution's
+ * store loop.  With x = dY
  * of a block's first convolution, addend = the shortcut gradient and relu_mask = the block input (the output of the
  * previous block's relu(bn3(.) + shortcut), resnet.py:66-68), y is the gradient that BatchNorm node needs with its ReLU
  * backward already applied, so dir_bn_bwd runs with relu = 0 and re-reads neither its saved output nor writes a
  * separate shortcut gradient.  addend, relu_mask: [N, Ho, Wo, Cout] bf16, either may be NULL; stats must be NULL when
  * one of them is given. */
-int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y, float* stats,
+int dir_conv_fwd_fused(const void* x, const void* w, const void* addend, const void* relu_mask, void* y, float* stats, int stats_rows,
                        int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, dir_stream_t stream);
 /* Data gradient at a projection block's input (imdb-wiki-dir/resnet.py:57-68: x feeds conv1 AND the stride-2 1x1
  * downsample conv): y = relu'(relu_mask) * bf16(bf16(conv(x, w)) + addend + up2(addend_s2)), stride 1.  addend_s2 is the
@@ -369,24 +345,29 @@ int dir_conv_dgrad_join(const void* x, const void* w, const void* addend, const 
  * the store loop: the result y is the gradient of the OUTPUT of a BatchNorm (bn1 / bn2 / bn3 of a Bottleneck, resnet.py:45-50)
  * whose input is bn_x ([N, Ho, Wo, Cout] bf16, the geometry of y); stats [rows][2][Cout] f32 receives, per 128-row tile, the
  * sums of g and g * bn_x over the rows (g = y as stored, in bf16) — the `partial` operand of dir_bn_bwd_partials.
- * rows = dir_conv_stats_rows(N, Ho, Wo), x 4 for the stride-2 form (one block of rows per parity class).
+ * stats_rows = dir_conv_plan_rows(...) for the stride-1 forms, 4 x dir_conv_stats_rows(N, Ho, Wo) for the stride-2 form (one block of
+ * rows per parity class); checked by the launch.
  * bn_gamma / bn_beta / bn_mean / bn_rstd non-NULL: the BatchNorm is followed by a ReLU (no residual); g is taken under that
  * ReLU's mask, recomputed as bn_x * a + b > 0 with the forward's coefficients (the stored y stays unmasked). */
 int dir_conv_dgrad_bnstats(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
                            void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad, const void* bn_x,
                            const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_rstd,
-                           float* stats, dir_stream_t stream);
+                           float* stats, int stats_rows, dir_stream_t stream);
 /* The general stride-1 data gradient: dir_conv_dgrad_join, plus dir_conv_dgrad_bnstats when bn_x != NULL (then stats != NULL),
  * with the ReLU backward mask given either as the tensor itself (relu_mask, as above) or as the bit mask that
  * dir_bn_fwd_train_bits / dir_bn_apply_bits emitted for it (relu_mask_bits, [N*H*W][Cout / 8] bytes, bit j of a byte = channel
- * 8 b + j was positive): 1/16 of the bytes for the same decision.  At most one of the two. */
+ * 8 b + j was positive): 1/16 of the bytes for the same decision.  At most one of the two.  variant: DIR_CONV_* (0 = product). */
 int dir_conv_dgrad_ex(const void* x, const void* w, const void* addend, const void* addend_s2, const void* relu_mask,
                       const void* relu_mask_bits, void* y, int N, int H, int W, int Cin, int Cout, int R, int S, int pad,
                       const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                      const float* bn_rstd, float* stats, dir_stream_t stream);
+                      const float* bn_rstd, float* stats, int stats_rows, int variant, dir_stream_t stream);
 int dir_conv_dgrad_s2_bnstats(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
                               const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                              const float* bn_rstd, float* stats, dir_stream_t stream);
+                              const float* bn_rstd, float* stats, int stats_rows, dir_stream_t stream);
+/* dir_conv_dgrad_s2 / _bnstats (bn_x and stats both NULL or both given) with the kernel of the four launches forced (variant). */
+int dir_conv_dgrad_s2_ex(const void* dy, const void* wcls, void* dx, int N, int Ho, int Wo, int Cy, int Cx,
+                         const void* bn_x, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                         const float* bn_rstd, float* stats, int stats_rows, int variant, dir_stream_t stream);
 /* Stem convolution 7x7 / stride 2 / pad 3, 3 -> 64 channels (imdb-wiki-dir/resnet.py:79,129), MFMA without an im2col
  * buffer.  x [N, H, W, 3] bf16 (channels_last image), wpack = dir_stem_conv_prep_weights(w) with w the float32 master
  * weight [64][7][7][3] (= channels_last [64, 3, 7, 7]); y [N, Ho, Wo, 64] bf16; stats (may be NULL)
@@ -402,11 +383,9 @@ size_t dir_stem_conv_wgrad_workspace(int N, int H);
 int dir_stem_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, void* workspace,
                         size_t workspace_bytes, dir_stream_t stream);
 
-/* dir_conv_fwd with its K-loop variant forced, for A/B measurements and tests: 0 = the heuristic of dir_conv_fwd, 4 = the persistent ring kernel (DIR_EUNSUPPORTED when the geometry is not taken),
- * 5 = the 256 x 256 CU-tile kernel on 16 wavefronts (Cout % 256 == 0 and N*Ho*Wo % 256 == 0, else DIR_EUNSUPPORTED),
- * 6 = its 256 x 128 single-stage form on 8 wavefronts (two workgroups per CU; measured slower everywhere, kept for the probes),
- * 1 = register-staged loop (global -> VGPR -> ds_write), 2 = LDS-DMA loop (buffer_load ... lds, two stages). */
-int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int N, int H, int W, int Cin, int Cout,
+/* dir_conv_fwd with the kernel forced (variant = DIR_CONV_*), for tests and A/B measurements; stats_rows =
+ * dir_conv_plan_rows(..., 0, variant). */
+int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout,
                          int R, int S, int stride, int pad, int variant, dir_stream_t stream);
 
 /* K9w  weight gradient of the same convolution:  dw[co, r, s, ci] = sum_m dy[m, co] * x[gather(m, r, s), ci]
@@ -438,14 +417,7 @@ int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float*
  * no flip); out [B, S, S, 3] float32 or bf16 (dtype) = a channels_last [B, 3, S, S] tensor, float32 arithmetic exactly as
  * ToTensor / Normalize execute it ((u8 / 255 - 0.5) / 0.5; padding pixels -> -1). */
 int dir_augment_u8(const void* img, const int* params, void* out, int dtype, int B, int S, int pad, dir_stream_t stream);
-/* L2-resident re-read probe: `workgroups` workgroups each stream the same region_bytes (2-8 MB: L2 resident) `passes` times with
- * `depth` (4 | 8 | 16) independent 16-byte loads per lane in flight: the L2 -> CU delivery rate when the latency is covered
- * (to tell a latency-bound K loop from a bandwidth-bound one).  out: >= 4 * workgroups floats. */
-int dir_probe_l2_read(const void* src, float* out, size_t region_bytes, int workgroups, int passes, int depth, dir_stream_t stream);
-/* Test probe of the hardware-transposing LDS read the 3x3 weight gradient is built on: LDS holds the uint16 ramp 0, 1, 2, ...
- * (8192 elements); lane l of ONE wavefront issues ds_read_b64_tr_b16 at byte address addr_bytes[l] (8-byte aligned) and
- * out[4 l .. 4 l + 3] receives its four 16-bit results. */
-int dir_probe_tr16(const int* addr_bytes, void* out, dir_stream_t stream);
+
 
 
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC bf16 (resnet.py:82,131 nn.MaxPool2d) with one argmax byte (0..8 = r*3+s,
@@ -472,16 +444,14 @@ int dir_bn_relu_maxpool_bwd(const void* dy, const void* argmax, const void* x, v
                             void* workspace, size_t workspace_bytes, dir_stream_t stream);
 /* The same pair with the BatchNorm input AT THE ARGMAX kept by the forward (xmax [N, Ho, Wo, C] bf16, the bits of x as read): the
  * backward's reduction (sum g, sum g x) then streams three pooled-size tensors instead of gathering 2-byte elements out of the 4x
- * larger x. xmax == NULL: as the functions above. Identical results either way (same values, same summation order). */
+ * larger x, and the apply pass runs with one thread per 2 x 2 input block (four windows loaded once) instead of one per pixel.
+ * xmax == NULL: exactly the functions above (gather reduction, per-pixel apply).  Identical results either way (same values, same
+ * summation order): the older pair is the oracle of the newer one in tests/test_hip_bn.py. */
 int dir_bn_relu_maxpool_fwd_xmax(const void* x, const float* coef, void* y, void* argmax, void* xmax, int N, int H, int W, int C,
                                  dir_stream_t stream);
 int dir_bn_relu_maxpool_bwd_xmax(const void* dy, const void* argmax, const void* x, const void* xmax, void* dx, int N, int H, int W,
                                  int C, const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                                  void* workspace, size_t workspace_bytes, dir_stream_t stream);
-/* Measurement / test switch of the stem-tail backward (default 3): bit 0 = the reduction uses xmax when given, bit 1 = the apply pass
- * runs with one thread per 2 x 2 input block (four windows loaded once) instead of one per pixel. All modes are bit-identical.
- * Returns the previous mode. */
-int dir_stem_tail_set_mode(int mode);
 /* Second third of dir_bn_bwd on its own: partial [rows][2][C] f32 of (sum g, sum g*x) -> dgamma, dbeta and
  * coef [3][C] = (a, p, q) with dx = a g + p x + q. */
 int dir_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* save_mean,
@@ -572,20 +542,6 @@ size_t dir_tail_bwd_workspace(int B, int C);
 int dir_tail_bwd(const float* dpred, const float* dencoding, const int32_t* bins, const float* scale, const float* weight,
                  const float* encoding, int B, int HW, int C, int dtype, void* dx, float* dweight, float* dbias,
                  void* workspace, size_t workspace_bytes, dir_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Box calibration probes (measured STREAM-style HBM number and measured MFMA peak of THIS box, reported
- * next to the nominal 8 TB/s / 2.5 PFLOP/s).  Not part of the reference's path; bench.py times them with HIP events.
- *   dir_probe_stream_copy: dst[i] = src[i], 16 B per lane, 2048 workgroups grid-stride  (moves 2 * bytes)
- *   dir_probe_stream_read: read-only stream, wave-reduced, out >= 8192 floats           (moves bytes)
- *   dir_probe_stream_write: write-only stream                                           (moves bytes)
- *   dir_probe_mfma_bf16 / _f32: `iters` rounds of independent MFMA chains per wavefront, no memory traffic;
- *                          *flops (host, nullable) receives the FLOPs of the launch; out >= workgroups * 256 floats. */
-int dir_probe_stream_copy(const void* src, void* dst, size_t bytes, dir_stream_t stream);
-int dir_probe_stream_read(const void* src, float* out, size_t bytes, dir_stream_t stream);
-int dir_probe_stream_write(void* dst, size_t bytes, dir_stream_t stream);        /* write-only stream; bytes % 16384 == 0 */
-int dir_probe_mfma_bf16(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
-int dir_probe_mfma_f32(int workgroups, int iters, float* out, double* flops, dir_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -259,31 +259,30 @@ def test_stem_bn_relu_maxpool_matches_unfused():
 
 
 def test_stem_tail_backward_modes_bit_identical():
-    """dir_stem_tail_set_mode: the xmax-streaming reduction and the 2 x 2-block apply pass against the gather reduction and the
-    per-pixel apply pass (round 2), even and odd map sizes: dx, dgamma, dbeta equal bit for bit."""
-    from dirhip.pool import bn_relu_maxpool
+    """The stem tail's backward with the forward's xmax (streaming reduction + 2 x 2-block apply pass: dir_bn_relu_maxpool_*_xmax, what
+    dirhip.pool runs) against the older pair without it (gather reduction + per-pixel apply pass: dir_bn_relu_maxpool_fwd / _bwd), even
+    and odd map sizes: y, dx, dgamma, dbeta equal bit for bit. The form is chosen per call (xmax given or not), not by a switch."""
+    from dirhip import pool as P
     g = torch.Generator(device="cuda").manual_seed(16)
     for shape in ((8, 64, 112, 112), (3, 64, 9, 7), (2, 64, 10, 15), (2, 32, 8, 8)):
         x0 = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         c = shape[1]
         dy = None
         got = {}
-        for mode in (0, 1, 2, 3):
-            prev = L.lib().dir_stem_tail_set_mode(mode)
+        for use_xmax in (False, True):
+            prev = P.set_stem_tail_xmax(use_xmax)
             try:
                 bn = nn.BatchNorm2d(c).cuda()
                 with torch.no_grad():
                     bn.weight.copy_(torch.linspace(0.5, 1.5, c, device="cuda"))
                     bn.bias.copy_(torch.linspace(-0.4, 0.4, c, device="cuda"))
                 x = x0.clone().requires_grad_(True)
-                y = bn_relu_maxpool(x, bn, nn.MaxPool2d(3, 2, 1))
+                y = P.bn_relu_maxpool(x, bn, nn.MaxPool2d(3, 2, 1))
                 if dy is None:
                     dy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 y.backward(dy)
-                got[mode] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+                got[use_xmax] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
             finally:
-                L.lib().dir_stem_tail_set_mode(prev)
-        for mode in (1, 2, 3):
-            for a, b, name in zip(got[mode], got[0], ("y", "dx", "dgamma", "dbeta")):
-                assert torch.equal(a, b), (shape, mode, name)
-
+                P.set_stem_tail_xmax(prev)
+        for a, b, name in zip(got[True], got[False], ("y", "dx", "dgamma", "dbeta")):
+            assert torch.equal(a, b), (shape, name)

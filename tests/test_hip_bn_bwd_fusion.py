@@ -72,11 +72,11 @@ def test_dgrad_epilogue_sums_vs_float64(n, cy, cx, hw, k, extras, recompute):
     part2 = torch.empty_like(link.partial)
     L0 = __import__("dirhip._lib", fromlist=["lib"])
     L0.check(L0.lib().dir_conv_dgrad_bnstats(L0.ptr(dy), L0.ptr(w), L0.ptr(addend), None, L0.ptr(mask), L0.ptr(y2), n, hw, hw, cy, cx, k, k, k // 2,
-                                             *_bn_link_args(link), L0.ptr(part2), L0.stream_ptr(dy.device)), "dir_conv_dgrad_bnstats")
+                                             *_bn_link_args(link), L0.ptr(part2), part2.shape[0], L0.stream_ptr(dy.device)), "dir_conv_dgrad_bnstats")
     assert torch.equal(y2, y) and torch.equal(part2, link.partial)
     part = link.partial
     from dirhip import _lib as L
-    assert part is not None and part.shape == (L.lib().dir_conv_tile_rows(n, hw, hw, k, k, 1, k // 2), 2, cx)
+    assert part is not None and part.shape == (L.lib().dir_conv_plan_rows(n, hw, hw, cy, cx, k, k, 1, k // 2, 0, 0), 2, cx)
     s0, s1 = _expected_sums(y, link)
     got = part.double().sum(0)
     # per-tile float32 accumulation of <= 128 terms: 1e-5 of the scale of the column sums

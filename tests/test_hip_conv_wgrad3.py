@@ -19,7 +19,12 @@ def _cl(t):
 def test_transposing_lds_read_lane_mapping():
     """Within each 16-lane group, lane i supplies the address of 4 consecutive 16-bit elements (matrix row i >> 2, columns
     4 (i & 3) .. + 3) and receives column i of the 4 x 16 block, rows 0 .. 3 — with arbitrary (8-byte aligned) row addresses."""
+    import os
+    import sys
+    from conftest import ROOT
     from dirhip import _lib as L
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import toolslib                                    # the probe lives in tools/lib/libdir_hip_tools.so, not in the product library
     rng = np.random.default_rng(0)
     for trial in range(4):
         if trial == 0:       # the contiguous 4 x 16 block per group of the guide: lds[(l & 15) + 16 j + 64 (l >> 4)]
@@ -28,7 +33,7 @@ def test_transposing_lds_read_lane_mapping():
             addr = (rng.integers(0, 2040, 64) * 8).astype(np.int32)
         out = torch.empty(64 * 4, dtype=torch.int16, device="cuda")
         a = torch.as_tensor(addr).cuda()
-        L.check(L.lib().dir_probe_tr16(L.ptr(a), L.ptr(out), L.stream_ptr(a.device)), "dir_probe_tr16")
+        L.check(toolslib.lib().dir_probe_tr16(L.ptr(a), L.ptr(out), L.stream_ptr(a.device)), "dir_probe_tr16")
         got = out.cpu().numpy().astype(np.int64).reshape(64, 4) & 0xffff
         want = np.zeros((64, 4), np.int64)
         for l in range(64):

@@ -3,6 +3,7 @@ loud failure without a GPU, and the world_size-2 (gloo) statistic merge. No HIP 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -21,7 +22,22 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in dir_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib().dir_abi_version() == 1
+    # the product library exports product entry points only: no process-wide switches, no measurement probes or
+    # experiment kernels (weak #8: those live in tools/lib/libdir_hip_tools.so, declared in tools/csrc/dir_hip_tools.h)
+    import subprocess
+    exported = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+                if " T " in l and l.split()[-1].startswith("dir_")}
+    assert exported == declared, exported ^ declared
+    assert not [n for n in declared if "_set_" in n or "probe" in n]
+    assert "_set_" not in header
+    tools_header = open(os.path.join(ROOT, "tools", "csrc", "dir_hip_tools.h")).read()
+    tools_declared = set(re.findall(r"\b(dir_[a-z0-9_]+)\s*\(", tools_header))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import toolslib
+    assert tools_declared == set(toolslib.SIGNATURES) and not (tools_declared & declared)
+    th = ctypes.CDLL(toolslib.LIB_PATH)
+    assert all(hasattr(th, n) for n in tools_declared)
+    assert _lib.lib().dir_abi_version() == _lib.ABI_VERSION == 2
     assert _lib.lib().dir_error_string(-1) == b"invalid argument"
 
 
@@ -43,28 +59,23 @@ def test_conv_planning_entry_points_without_gpu():
     from dirhip import _lib
     L = _lib.lib()
     # 128-row tiles ...
-    assert L.dir_conv_tile_rows(256, 56, 56, 1, 1, 1, 0) == L.dir_conv_stats_rows(256, 56, 56) == 6272
-    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 2, 1) == L.dir_conv_stats_rows(256, 28, 28) == 1568
-    assert L.dir_conv_tile_rows(256, 7, 7, 3, 3, 1, 1) == 98                     # 7x7 maps: not a patch-kernel shape
+    assert L.dir_conv_plan_rows(256, 56, 56, 64, 256, 1, 1, 1, 0, 0, 0) == L.dir_conv_stats_rows(256, 56, 56) == 6272
+    assert L.dir_conv_plan_rows(256, 56, 56, 128, 128, 3, 3, 2, 1, 0, 0) == L.dir_conv_stats_rows(256, 28, 28) == 1568
+    assert L.dir_conv_plan_rows(256, 7, 7, 512, 512, 3, 3, 1, 1, 0, 0) == 98                     # 7x7 maps: not a patch-kernel shape
     # ... chunks of whole image rows for the patch-staged 3x3 / stride-1 layers (2 / 4 / 7 rows per chunk)
-    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 256 * 28
-    assert L.dir_conv_tile_rows(256, 28, 28, 3, 3, 1, 1) == 256 * 7
-    assert L.dir_conv_tile_rows(256, 14, 14, 3, 3, 1, 1) == 256 * 2
-    assert L.dir_conv_tile_rows(3, 56, 28, 3, 3, 1, 1) == L.dir_conv_stats_rows(3, 56, 28)   # not square
-    assert L.dir_conv_tile_rows(0, 56, 56, 3, 3, 1, 1) == 0
-    prev = L.dir_conv_set_patch3x3(0)
-    try:
-        assert prev == 1 and L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 6272
-    finally:
-        assert L.dir_conv_set_patch3x3(prev) == 0
-    assert L.dir_conv_tile_rows(256, 56, 56, 3, 3, 1, 1) == 256 * 28
+    assert L.dir_conv_plan_rows(256, 56, 56, 64, 64, 3, 3, 1, 1, 0, 0) == 256 * 28
+    assert L.dir_conv_plan_rows(256, 28, 28, 128, 128, 3, 3, 1, 1, 0, 0) == 256 * 7
+    assert L.dir_conv_plan_rows(64, 14, 14, 256, 256, 3, 3, 1, 1, 0, 0) == 64 * 2
+    assert L.dir_conv_plan_rows(0, 56, 56, 64, 64, 3, 3, 1, 1, 0, 0) == 0
+    # the kernel is an argument of the launch (no process-wide switch): the same layer through the 128-row tile kernel
+    assert L.dir_conv_plan_rows(256, 56, 56, 64, 64, 3, 3, 1, 1, 0, _lib.CONV_TILE_REG) == 6272
     # all-taps weight gradient: 256 partials of [64][9][64] floats whatever the channel count, per-tap form for other shapes
     for c, hw in ((64, 56), (128, 28), (256, 14), (512, 7)):
         assert L.dir_conv_wgrad3x3_workspace(256, hw, hw, c, c) == 256 * 64 * 9 * 64 * 4
     assert L.dir_conv_wgrad3x3_workspace(1, 7, 7, 64, 64) == 1 * 64 * 9 * 64 * 4          # one chunk: one split
     assert L.dir_conv_wgrad3x3_workspace(256, 112, 112, 64, 64) == 0 and L.dir_conv_wgrad3x3_workspace(256, 56, 56, 96, 64) == 0
     assert L.dir_conv_wgrad3x3(None, None, None, 256, 56, 56, 64, 64, None, 0, None) == -1
-    assert L.dir_conv_dgrad_ex(None, None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 0, None, None, None, None, None, None, None) == -1
+    assert L.dir_conv_dgrad_ex(None, None, None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 0, None, None, None, None, None, None, 0, 0, None) == -1
     assert L.dir_bn_bwd_partials(None, None, None, _lib.DIR_BF16, 64, 64, None, None, None, None, None, None, 0, None, 0, None, 0, None) == -1
     assert L.dir_augment_u8(None, None, None, _lib.DIR_F32, 1, 8, 16, None) == -1
     assert L.dir_conv_wgrad_reduce_splits(None, 1, 4, None, None) == -1

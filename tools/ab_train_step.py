@@ -1,6 +1,6 @@
 """In-process A/B of whole training steps (B=256, bf16 product path) with one switch flipped: alternating rounds of `steps`
-train steps each, wall clock per step. Switches: patch3 (dir_conv_set_patch3x3), wgrad3 (conv.set_wgrad3_all_taps), bnfuse
-(resnet.set_bn_bwd_fusion), relubits (bn.set_relu_bits), ring (dir_conv_set_ring).   python tools/ab_train_step.py patch3 [rounds] [steps]"""
+train steps each, wall clock per step. Switches: wgrad3 (conv.set_wgrad3_all_taps), bnfuse (resnet.set_bn_bwd_fusion),
+relubits (bn.set_relu_bits), joinbwd, wgradside, stemtail.   python tools/ab_train_step.py wgrad3 [rounds] [steps] [train|tail]"""
 import os
 import sys
 import time
@@ -23,7 +23,11 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
     what = sys.argv[4] if len(sys.argv) > 4 else "train"          # "train" steps or epoch-"tail" forwards (one per batch)
-    setter = {"patch3": lambda v: L.lib().dir_conv_set_patch3x3(int(v)), "patch3s": lambda v: L.lib().dir_conv_set_patch3x3(1 if v else 2), "resident": lambda v: L.lib().dir_conv_set_patch3x3(3 if v else 1), "joinbwd": B.set_join_bwd, "wgrad3": C.set_wgrad3_all_taps, "bnfuse": R.set_bn_bwd_fusion, "relubits": B.set_relu_bits, "ring": lambda v: L.lib().dir_conv_set_ring(int(v)), "bnfin": lambda v: L.lib().dir_bn_set_fused_finalize(int(v)), "bigkt32": lambda v: L.lib().dir_conv_set_big_thresholds(32 if v else 16, 150), "bigkt8": lambda v: L.lib().dir_conv_set_big_thresholds(8 if v else 16, 150), "bigt300": lambda v: L.lib().dir_conv_set_big_thresholds(16, 300 if v else 150), "bigt90": lambda v: L.lib().dir_conv_set_big_thresholds(16, 90 if v else 150), "tall": lambda v: L.lib().dir_conv_set_big(5 if v else 1), "big": lambda v: L.lib().dir_conv_set_big(1 if v else 0), "stemtail": lambda v: L.lib().dir_stem_tail_set_mode(3 if v else 0), "stemtail1": lambda v: L.lib().dir_stem_tail_set_mode(1 if v else 0), "stemtail2": lambda v: L.lib().dir_stem_tail_set_mode(2 if v else 0), "wgradside": C.set_wgrad_side_stream, "bnchunk2": lambda v: L.lib().dir_bn_set_apply_chunk(2 if v else 0), "bnchunk4": lambda v: L.lib().dir_bn_set_apply_chunk(4 if v else 0), "bnchunk8": lambda v: L.lib().dir_bn_set_apply_chunk(8 if v else 0), "bnchunk16": lambda v: L.lib().dir_bn_set_apply_chunk(16 if v else 0), "bncap512": lambda v: L.lib().dir_bn_set_grid_cap(512 if v else 768), "bncap1024": lambda v: L.lib().dir_bn_set_grid_cap(1024 if v else 768), "bncap1536": lambda v: L.lib().dir_bn_set_grid_cap(1536 if v else 768), "bncap2048": lambda v: L.lib().dir_bn_set_grid_cap(2048 if v else 768)}[which]
+    from dirhip import pool as P
+    # Python-level wiring switches only: the C-ABI has no process-wide kernel switches any more (kernel variants are per-launch arguments;
+    # to A/B two builds of a kernel use tools/ab_two_libs.py)
+    setter = {"joinbwd": B.set_join_bwd, "wgrad3": C.set_wgrad3_all_taps, "bnfuse": R.set_bn_bwd_fusion, "relubits": B.set_relu_bits,
+              "wgradside": C.set_wgrad_side_stream, "stemtail": P.set_stem_tail_xmax}[which]
 
     class A:
         batch, epoch_len, gpus = 256, 8, 1

@@ -117,7 +117,7 @@ for ci, co, h in SH:
     w = (torch.randn(co, ci, 1, 1, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     st = torch.empty(L.lib().dir_conv_stats_rows(B, h, h), 2, co, dtype=torch.float32, device=dev)
     def run(i):
-        L.check(L.lib().dir_conv_fwd_variant(L.ptr(xs[i % nbuf]), L.ptr(w), L.ptr(ys[i % nbuf]), L.ptr(st), B, h, h, ci, co, 1, 1, 1, 0, 0,
+        L.check(L.lib().dir_conv_fwd_variant(L.ptr(xs[i % nbuf]), L.ptr(w), L.ptr(ys[i % nbuf]), L.ptr(st), st.shape[0], B, h, h, ci, co, 1, 1, 1, 0, 0,
                                              L.stream_ptr(dev)), "conv")
     for i in range(3): run(i)
     best = 1e9
@@ -173,7 +173,7 @@ for ci, co, h in [(64, 256, 56), (128, 512, 28), (512, 128, 28), (256, 1024, 14)
     dbg = torch.zeros(nb, 5, dtype=torch.int64, device=dev)
     assert raw.dir_dbg_set(dbg.data_ptr()) == 0
     for i in range(3):
-        L.check(lib.dir_conv_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(st), B, h, h, ci, co, 1, 1, 1, 0, 0, L.stream_ptr(dev)), "conv")
+        L.check(lib.dir_conv_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(st), st.shape[0], B, h, h, ci, co, 1, 1, 1, 0, 0, L.stream_ptr(dev)), "conv")
     torch.cuda.synchronize()
     d = dbg.cpu().double()
     t0 = d[:, 0].min()

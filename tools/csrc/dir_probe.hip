@@ -7,6 +7,7 @@
 //   dir_probe_mfma_bf16   : 8 independent v_mfma_f32_32x32x16_bf16 accumulator chains per wavefront, no memory traffic
 //   dir_probe_mfma_f32    : the same with v_mfma_f32_32x32x2_f32 (the exact-f32 matrix path of the parity mode)
 #include "dir_common.h"
+#include "dir_hip_tools.h"
 
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 pb_bf16x8;
@@ -177,5 +178,28 @@ extern "C" int dir_probe_mfma_f32(int workgroups, int iters, float* out, double*
     hipLaunchKernelGGL((probe_mfma_f32_kernel<4>), dim3(workgroups), dim3(DIR_TPB), 0, dir_s(stream), iters, out);
     DIR_LAUNCH_CHECK();
     if (flops) *flops = (double)workgroups * 4.0 * iters * 4.0 * (2.0 * 32 * 32 * 2);
+    return DIR_OK;
+}
+
+// ---- probe of the hardware-transposing LDS read the 3x3 weight gradient is built on (tests/test_hip_conv_wgrad3.py pins the lane
+// mapping with it): LDS holds the uint16 ramp 0, 1, 2, ...; lane l of ONE wavefront reads at byte address addr[l]
+namespace {
+typedef __attribute__((ext_vector_type(4))) __bf16 pb_bf16x4;
+__global__ void __launch_bounds__(64) tr16_probe_kernel(const int* __restrict__ addr, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t ramp[8192];
+    for (int i = threadIdx.x; i < 8192; i += 64) ramp[i] = (uint16_t)i;
+    __syncthreads();
+    typedef __attribute__((address_space(3))) pb_bf16x4* lds_v4_t;
+    const pb_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(reinterpret_cast<const unsigned char*>(ramp) + addr[threadIdx.x]));
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)(bits >> (16 * j));
+}
+}  // namespace
+
+extern "C" int dir_probe_tr16(const int* addr_bytes, void* out, dir_stream_t stream) {
+    DIR_RETURN_IF(!addr_bytes || !out, DIR_EINVAL);
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, dir_s(stream), addr_bytes, static_cast<uint16_t*>(out));
+    DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

@@ -1,5 +1,5 @@
 """Measured peaks of THIS box: STREAM-style HBM copy / read bandwidth and the bf16 / f32 MFMA issue peak,
-through the dir_probe_* entry points of libdir_hip.so, timed with HIP events on the launch stream. Prints one JSON object;
+through the dir_probe_* entry points of tools/lib/libdir_hip_tools.so, timed with HIP events on the launch stream. Prints one JSON object;
 `python tools/measure_peaks.py > gpurun_out/peaks.json` (committed as profiles/rNN_peaks.json together with rocminfo)."""
 import ctypes
 import json
@@ -30,7 +30,9 @@ def ev(fn, iters, warm=3):
 
 def measure(device=None):
     dev = device or torch.device("cuda", torch.cuda.current_device())
-    lib = L.lib()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import toolslib
+    lib = toolslib.lib()
     out = {"device": torch.cuda.get_device_name(dev), "nominal": {"hbm_GBs": 8000.0, "bf16_mfma_TFs": 2500.0, "f32_mfma_TFs": 157.3}}
     nbytes = 2 << 30                                   # 2 GiB src + 2 GiB dst: far beyond the 256 MB Infinity Cache
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)

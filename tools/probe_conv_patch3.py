@@ -19,12 +19,12 @@ def main():
         xs = [torch.randn(n, c, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
         ys = [torch.empty(n, c, hw, hw, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
         w = (torch.randn(c, c, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        rows = max(L.lib().dir_conv_stats_rows(n, hw, hw), L.lib().dir_conv_tile_rows(n, hw, hw, 3, 3, 1, 1))
-        st = torch.empty(rows, 2, c, dtype=torch.float32, device=dev)
+        rows = {v: L.lib().dir_conv_plan_rows(n, hw, hw, c, c, 3, 3, 1, 1, 0, v) for v in (1, 2, 3)}
+        st = torch.empty(max(rows.values()), 2, c, dtype=torch.float32, device=dev)
         res = {}
         for v in (1, 2, 3):
             def run(i):
-                L.check(L.lib().dir_conv_fwd_variant(L.ptr(xs[i % nbuf]), L.ptr(w), L.ptr(ys[i % nbuf]), L.ptr(st), n, hw, hw, c, c, 3, 3, 1, 1, v,
+                L.check(L.lib().dir_conv_fwd_variant(L.ptr(xs[i % nbuf]), L.ptr(w), L.ptr(ys[i % nbuf]), L.ptr(st), rows[v], n, hw, hw, c, c, 3, 3, 1, 1, v,
                                                      L.stream_ptr(dev)), "variant")
             for i in range(3):
                 run(i)

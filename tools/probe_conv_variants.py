@@ -20,19 +20,8 @@ SH = [(64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256
 
 
 def run(x, w, y, st, n, h, cin, cout, k, stride, pad, variant):
-    if variant == 10:                                 # the heuristic with the persistent ring kernel switched off (round-2 kernels)
-        prev = L.lib().dir_conv_set_ring(0)
-        try:
-            return run(x, w, y, st, n, h, cin, cout, k, stride, pad, 0)
-        finally:
-            L.lib().dir_conv_set_ring(prev)
-    if variant >= 40:                                 # ring kernel with measurement flags (41 = no MFMA, 42 = no DMA)
-        prev = L.lib().dir_conv_set_ring(1 | ((variant - 40) << 4))
-        try:
-            return run(x, w, y, st, n, h, cin, cout, k, stride, pad, 4)
-        finally:
-            L.lib().dir_conv_set_ring(prev)
-    L.check(L.lib().dir_conv_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(st), n, h, h, cin, cout, k, k, stride, pad, variant,
+    rows = L.lib().dir_conv_plan_rows(n, h, h, cin, cout, k, k, stride, pad, 0, variant) if st is not None else 0
+    L.check(L.lib().dir_conv_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(st), rows, n, h, h, cin, cout, k, k, stride, pad, variant,
                                          L.stream_ptr(x.device)), "dir_conv_fwd_variant")
 
 
@@ -53,7 +42,7 @@ def main():
             xs = [torch.randn(B, ci, hh, hh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
             ys = [torch.empty(B, co, hout, hout, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
             w = (torch.randn(co, ci, k, k, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            rows = max(L.lib().dir_conv_stats_rows(B, hout, hout), L.lib().dir_conv_tile_rows(B, hh, hh, k, k, s_, pad))
+            rows = max([L.lib().dir_conv_plan_rows(B, hh, hh, ci, co, k, k, s_, pad, 0, v) for v in variants] + [1])
             stt = torch.empty(rows, 2, co, dtype=torch.float32, device=dev) if kind == "fwd" else None
             flop = 2.0 * B * hout * hout * co * ci * k * k
             roof_us = max(flop / 2.5e15, nbytes / 8e12) * 1e6

@@ -12,7 +12,9 @@ from dirhip import _lib as L  # noqa: E402
 
 def main():
     dev = torch.device("cuda")
-    lib = L.lib()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import toolslib
+    lib = toolslib.lib()
     src = torch.empty(64 << 20, dtype=torch.uint8, device=dev).random_(0, 255)
     out = torch.empty(1 << 16, dtype=torch.float32, device=dev)
     st = L.stream_ptr(dev)
