@@ -111,6 +111,7 @@ class DataParallelEngine(nn.Module):
         # (SUM(mean_1 + local_2) / world = mean_1 + mean_2, what AVG gives on RCCL); `bucket_scale_kernels` counts those passes.
         self._native_avg = bool(self._comm and dist.get_backend(process_group) == "nccl")
         self._accumulating = False
+        self._decided = False
         if channels_last:
             self.module.to(memory_format=torch.channels_last)
         if self._comm and broadcast_from_rank0:
@@ -136,12 +137,22 @@ class DataParallelEngine(nn.Module):
                 out = self.module(inputs, *args, **kwargs)
         else:
             out = self.module(inputs, *args, **kwargs)
-        if self._comm and not self._native_avg and self.training and torch.is_grad_enabled() and not self._accumulating:
-            inv = 1.0 / self.world
+        if self._comm and not self._native_avg and self.training and torch.is_grad_enabled():
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(t, torch.Tensor) and t.requires_grad:
-                    t.register_hook(lambda g, inv=inv: None if g is None else g * inv)        # (the prediction [B, 1]: every parameter gradient flows through it)
+                    t.register_hook(self._scale_output_grad)                                  # (the prediction [B, 1]: every parameter gradient flows through it)
         return out
+
+    def _scale_output_grad(self, g):
+        """Fires when the backward pass reaches the network output, i.e. before any parameter gradient of this pass exists: the moment
+        to see whether the parameters still HOLD gradients (train loops call zero_grad() between forward and backward, so the forward
+        cannot know)."""
+        if g is None:
+            return None
+        if not self._decided:
+            self._decided = True
+            self._accumulating = any(p.grad is not None for b in (self._buckets or []) for p in b.params)
+        return None if self._accumulating else g * (1.0 / self.world)
 
     # ---- gradient buckets -------------------------------------------------------------------------
     def _prepare_buckets(self):
@@ -176,7 +187,8 @@ class DataParallelEngine(nn.Module):
             b.pending = len(b.params)
             b.work = None
         self._callback_queued = False
-        self._accumulating = bool(self._comm and any(p.grad is not None for p in params))
+        self._accumulating = False          # decided when the backward pass starts (_scale_output_grad)
+        self._decided = False
 
     def _on_grad_ready(self, p):
         if not self._callback_queued:

@@ -102,7 +102,9 @@ def test_stride2_dgrad_epilogue_sums_vs_float64(recompute):
     rows = L.lib().dir_conv_stats_rows(n, ho, ho)
     part = torch.empty(4 * rows, 2, cx, dtype=torch.float32, device="cuda")
     st = L.stream_ptr(dy.device)
-    L.check(L.lib().dir_conv_dgrad_s2_bnstats(L.ptr(dy), L.ptr(wcls), L.ptr(dx), n, ho, ho, cy, cx, *_bn_link_args(link), L.ptr(part), st), "s2 bnstats")
+    L.check(L.lib().dir_conv_dgrad_s2_bnstats(L.ptr(dy), L.ptr(wcls), L.ptr(dx), n, ho, ho, cy, cx, *_bn_link_args(link), L.ptr(part), part.shape[0], st), "s2 bnstats")
+    # a list sized for another tiling is refused, not overrun
+    assert L.lib().dir_conv_dgrad_s2_bnstats(L.ptr(dy), L.ptr(wcls), L.ptr(dx), n, ho, ho, cy, cx, *_bn_link_args(link), L.ptr(part), rows, st) == -1
     L.check(L.lib().dir_conv_dgrad_s2(L.ptr(dy), L.ptr(wcls), L.ptr(dx_plain), n, ho, ho, cy, cx, st), "s2")
     assert torch.equal(dx, dx_plain)
     # ... and it is the data gradient of the stride-2 convolution (float32 reference on the bf16 operands)

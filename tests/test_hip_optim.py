@@ -153,6 +153,8 @@ def test_adam_loads_reference_layout_state_into_channels_last_model():
     torch.cuda.synchronize()
     for a, b in zip(ours_p, ref_p):
         assert ours.state[a]["exp_avg"].stride() == a.stride()
-        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
-        assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-6, atol=1e-12)
-        assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-6, atol=1e-20)
+        # (different gradients every step: exp_avg cancels, so one float32 rounding — torch's kernels contract a + w * (b - a) into an
+        # fma, ours does not — is an ABSOLUTE 1e-8, not a relative one; a permuted moment would be off by O(0.1))
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
+        assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-8)

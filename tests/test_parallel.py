@@ -40,6 +40,7 @@ def _worker(rank, world, port, tmp):
         loss.backward()
         opt.step()
     assert len(eng._buckets) >= 2
+    assert eng.stats["bucket_scale_kernels"] == 0           # zero_grad() between forward and backward: not an accumulating pass
     for b in eng._buckets:                                  # gradient views share the parameters' memory layout
         for prm, v in zip(b.params, b.views):
             assert v.stride() == prm.stride() and prm.grad.data_ptr() == v.data_ptr()
