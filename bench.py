@@ -435,11 +435,14 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
                "workers": workers, "batch": batch, "consumer_images_per_sec": consumer_img_s}
 
         def rate(raw, budget, batch=batch):
+            from dirhip.datasets import DeviceResize, ragged_collate
             ds = IMDBWIKI(df, tmp, img_size=224, split="train", raw=raw)
             n_img = 5000 * batch
             dl = DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds, replacement=True, num_samples=n_img), num_workers=workers,
-                            pin_memory=True, drop_last=True, prefetch_factor=4, persistent_workers=False)
+                            pin_memory=True, drop_last=True, prefetch_factor=4, persistent_workers=False,
+                            collate_fn=ragged_collate if raw == "decoded" else None)
             aug = DeviceAugment(224, train=True, dtype=torch.bfloat16) if raw else None
+            rz = DeviceResize(224, device) if raw == "decoded" else None
             it = iter(dl)
             for _ in range(3):                                # worker start-up + first batches
                 next(it)
@@ -448,9 +451,12 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
             n = 0
             t_dev = 0.0
             while time.perf_counter() - t0 < budget:
-                img, lab, w = next(it)
+                b = next(it)
                 t1 = time.perf_counter()
-                img = img.to(device, non_blocking=True)
+                if rz is not None:
+                    img, lab, w = rz(b[0], b[1]), b[2], b[3]
+                else:
+                    img, lab, w = b[0].to(device, non_blocking=True), b[1], b[2]
                 x = aug(img) if raw else img.contiguous(memory_format=torch.channels_last)
                 lab.to(device, non_blocking=True); w.to(device, non_blocking=True)
                 torch.cuda.synchronize(device)
@@ -459,9 +465,13 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
             dt = time.perf_counter() - t0
             del it, dl
             return n * batch / dt, t_dev / max(1, n) * 1e3, tuple(x.shape), str(x.dtype)
-        r, ms, shp, dt_ = rate(True, seconds * 0.6)
+        r, ms, shp, dt_ = rate(True, seconds * 0.4)
         out["uint8_files_gpu_augment"] = {"images_per_sec": r, "h2d_plus_dir_augment_u8_ms_per_batch": ms, "network_input": f"{shp} {dt_} channels_last",
                                           "keeps_up_with_consumer": bool(r >= consumer_img_s)}
+        r, ms, shp, dt_ = rate("decoded", seconds * 0.4)
+        out["decode_only_workers_gpu_resize_augment"] = {"images_per_sec": r, "h2d_plus_dir_resize_u8_plus_dir_augment_u8_ms_per_batch": ms,
+                                                         "network_input": f"{shp} {dt_} channels_last", "keeps_up_with_consumer": bool(r >= consumer_img_s),
+                                                         "what": "workers: PIL decode only (file-size uint8, ragged batch); GPU: dir_resize_u8 (Pillow bilinear, bit-exact) + dir_augment_u8"}
         # the reference's own host transform chain (float32 CHW out of __getitem__), per core, in this process: decode + Resize +
         # pad / crop / flip + ToTensor + Normalize
         ds_f = IMDBWIKI(df, tmp, img_size=224, split="train")
@@ -475,16 +485,23 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
         for i in range(96):
             ds_r[i]
         per_core_raw = 96 / (time.perf_counter() - t0)
-        out["per_core_images_per_sec"] = {"decode_resize_uint8": per_core_raw, "decode_resize_host_float_chain": per_core,
-                                          "cores_needed_for_consumer_uint8": consumer_img_s / per_core_raw}
+        ds_d = IMDBWIKI(df, tmp, img_size=224, split="train", raw="decoded")
+        t0 = time.perf_counter()
+        for i in range(96):
+            ds_d[i]
+        per_core_dec = 96 / (time.perf_counter() - t0)
+        out["per_core_images_per_sec"] = {"decode_only_uint8": per_core_dec, "decode_resize_uint8": per_core_raw, "decode_resize_host_float_chain": per_core,
+                                          "cores_needed_for_consumer_uint8": consumer_img_s / per_core_raw,
+                                          "cores_needed_for_consumer_decode_only": consumer_img_s / per_core_dec}
         host_cores = os.cpu_count() or 1
         out["host_cores"] = host_cores
-        out["cores_needed_for_8_gpus"] = {"host_decode_plus_resize_uint8": n_gpus_target * consumer_img_s / per_core_raw,
+        out["cores_needed_for_8_gpus"] = {"decode_only_gpu_resize": n_gpus_target * consumer_img_s / per_core_dec,
+                                          "host_decode_plus_resize_uint8": n_gpus_target * consumer_img_s / per_core_raw,
                                           "reference_host_float_chain": n_gpus_target * consumer_img_s / per_core,
                                           "consumer_images_per_sec_per_gpu": consumer_img_s, "gpus": n_gpus_target,
-                                          "verdict": "host-bound at 8 GPUs on this box" if n_gpus_target * consumer_img_s / per_core_raw > host_cores
-                                                     else "the box's cores can feed 8 GPUs"}
-        out["note"] = ("decode + Resize are host PIL in loader workers (no GPU JPEG decoder in this image); the rates are the loaders' own, not "
+                                          "verdict": "host-bound at 8 GPUs on this box" if n_gpus_target * consumer_img_s / per_core_dec > host_cores
+                                                     else "the box's cores can feed 8 GPUs (decode-only workers, Resize + augmentation on the GPUs)"}
+        out["note"] = ("decode is host PIL in loader workers (no GPU JPEG decoder in this image), Resize either there or on the GPU; the rates are the loaders' own, not "
                        "overlapped with training; `value` of this bench uses HBM-resident synthetic batches")
         return out
     finally:

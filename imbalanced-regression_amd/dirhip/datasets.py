@@ -2,8 +2,9 @@
 
 Same constructor and ``__getitem__ -> (img f32[3,S,S], label f32[1], weight f32[1])`` contract; ``.weights`` comes
 from the native LDS routine (``dirhip.lds.prepare_weights`` -> ``dir_lds_weights``, bit-exact with the reference's
-numpy/scipy arithmetic). Image decoding and Resize are host-side PIL (the reference uses torchvision
-transforms, which this image does not ship); the rest of the transform chain — RandomCrop(pad 16) -> RandomHorizontalFlip ->
+numpy/scipy arithmetic). Image decoding is host-side PIL (the reference uses torchvision transforms, which this image does not
+ship; no GPU JPEG decoder either); Resize is host-side PIL by default and, with ``raw="decoded"`` + ``DeviceResize``, three HIP launches
+on the ragged uint8 batch (``dir_resize_u8``: Pillow's bilinear arithmetic bit for bit); the rest of the transform chain — RandomCrop(pad 16) -> RandomHorizontalFlip ->
 [0,1] -> Normalize(.5, .5) (datasets.py:38-53) — runs either on the host (numpy, the default ``__getitem__`` contract) or,
 with ``raw=True`` + ``DeviceAugment``, as ONE HIP launch per batch on the uint8 images (``dir_augment_u8``):
 a quarter of the host->device bytes, no float32 round trip, bf16 NHWC output straight into the MFMA stem. ``SyntheticAgeDataset`` produces device-resident random batches with the
@@ -65,11 +66,63 @@ class DeviceAugment:
         return out.permute(0, 3, 1, 2)                          # [B, 3, S, S] view with channels_last strides
 
 
+def ragged_collate(samples):
+    """collate_fn for ``raw="decoded"`` datasets: images of different sizes cannot be stacked, so a batch is
+    ``(flat uint8 [sum H*W*3], sizes int64 [B, 2] = (H, W), labels float32 [B, 1], weights float32 [B, 1][, further per-sample items])`` —
+    ``flat`` and ``sizes`` are the input of ``DeviceResize``."""
+    imgs = [s[0] for s in samples]
+    flat = torch.cat([im.reshape(-1) for im in imgs])
+    sizes = torch.tensor([[im.shape[0], im.shape[1]] for im in imgs], dtype=torch.int64)
+    labels = torch.from_numpy(np.stack([np.asarray(s[1], dtype=np.float32) for s in samples]))
+    weights = torch.from_numpy(np.stack([np.asarray(s[2], dtype=np.float32) for s in samples]))
+    extra = tuple(torch.as_tensor([s[i] for s in samples]) for i in range(3, len(samples[0])))      # e.g. the shard-padding flag
+    return (flat, sizes, labels, weights) + extra
+
+
+class DeviceResize:
+    """GPU side of ``transforms.Resize((S, S))`` (datasets.py:41,49) for ``raw="decoded"`` batches: ``resize(flat, sizes)`` takes the
+    ragged uint8 batch of ``ragged_collate`` (host or device tensors; the copy to the device happens here, non-blocking when pinned) and
+    returns the uint8 ``[B, S, S, 3]`` device batch ``DeviceAugment`` consumes. Three HIP launches (``dir_resize_u8``), bit-identical to
+    Pillow's bilinear resize; no CPU fallback."""
+
+    def __init__(self, img_size, device=None):
+        self.img_size = int(img_size)
+        self.device = device
+
+    def __call__(self, flat, sizes):
+        from . import _lib as L
+        dev = torch.device(self.device) if self.device is not None else (flat.device if flat.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+        if dev.type != "cuda":
+            raise L.DirHipError(f"DeviceResize: target device {dev}; the resize kernels run only on the GPU")
+        s = self.img_size
+        sizes = torch.as_tensor(sizes, dtype=torch.int64).cpu()
+        assert flat.dtype == torch.uint8 and flat.dim() == 1 and sizes.dim() == 2 and sizes.shape[1] == 2
+        b = sizes.shape[0]
+        h, w = sizes[:, 0], sizes[:, 1]
+        nbytes = h * w * 3
+        assert int(nbytes.sum()) == flat.numel() and int(h.min()) > 0 and int(w.min()) > 0
+        src_off = torch.cumsum(nbytes, 0) - nbytes
+        tmp = (h * s * 3 + 15) // 16 * 16                           # intermediate [H][S][3] of every image, 16-byte aligned
+        tmp_off = torch.cumsum(tmp, 0) - tmp
+        table = torch.stack([src_off, h, w, tmp_off], 1).contiguous()
+        lib = L.lib()
+        kmax = max(lib.dir_resize_ksize(int(h.max()), s), lib.dir_resize_ksize(int(w.max()), s))
+        ws_bytes = lib.dir_resize_u8_workspace(b, s, kmax, int(tmp.sum()))
+        flat_d = flat.to(dev, non_blocking=True)
+        table_d = table.to(dev, non_blocking=True)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, s, s, 3), dtype=torch.uint8, device=dev)
+        L.check(lib.dir_resize_u8(L.ptr(flat_d), L.ptr(table_d), L.ptr(out), b, s, int(h.max()), kmax, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "dir_resize_u8")
+        return out
+
+
 class _AgeDataset(data.Dataset):
     def __init__(self, df, data_dir, img_size, split='train', reweight='none',
                  lds=False, lds_kernel='gaussian', lds_ks=5, lds_sigma=2, raw=False):
         # raw=True (extension): __getitem__ returns the decoded, resized uint8 HWC image instead of the transformed float
-        # tensor; the rest of the transform chain then runs on the GPU (DeviceAugment)
+        # tensor; the rest of the transform chain then runs on the GPU (DeviceAugment). raw="decoded": decoded only, at the file's
+        # own size — Resize runs on the GPU too (DeviceResize; batches through ragged_collate)
         self.raw = raw
         self.df = df
         self.data_dir = data_dir
@@ -90,6 +143,10 @@ class _AgeDataset(data.Dataset):
 
         def transform(img):
             from PIL import Image
+            if self.raw == "decoded":
+                # decode only: the image leaves the worker at its file size (uint8 [H, W, 3]); Resize runs on the GPU (DeviceResize,
+                # dir_resize_u8: Pillow's bilinear arithmetic bit for bit) in front of DeviceAugment — batches need `ragged_collate`
+                return torch.from_numpy(np.array(np.asarray(img, dtype=np.uint8), copy=True))
             img = img.resize((size, size), Image.BILINEAR)
             arr = np.asarray(img, dtype=np.uint8)
             if self.raw:

@@ -87,6 +87,8 @@ def build_parser(dataset_default='imdb_wiki'):
     p.add_argument('--max_steps', type=int, default=0, help='truncate every epoch to this many steps (0 = full)')
     p.add_argument('--gpu_augment', action='store_true', help='image files only: the DataLoader yields decoded, resized uint8 images and '
                    'RandomCrop / flip / ToTensor / Normalize run as one HIP kernel per batch (dir_augment_u8) instead of per image on the host')
+    p.add_argument('--gpu_resize', action='store_true', help='image files only, implies --gpu_augment: loader workers only DECODE; Resize((S, S)) runs on the '
+                   'GPU as well (dir_resize_u8: Pillow\'s bilinear arithmetic bit for bit, on the ragged uint8 batch), then dir_augment_u8')
     p.add_argument('--overwrite', action='store_true', help='delete an existing run folder of the same name (the reference asks on '
                    'the terminal; without a terminal nothing is deleted unless this flag is given)')
     p.set_defaults(augment=True)
@@ -117,10 +119,14 @@ class _NullTB:
         pass
 
 
-def _loader_batches(loader, device, augment=None):
+def _loader_batches(loader, device, augment=None, resize=None):
     """``augment``: a ``datasets.DeviceAugment`` when the dataset is in raw mode — the uint8 batch goes over PCIe (a quarter of the
-    float32 bytes) and crop / flip / normalise / cast run as one kernel on the GPU."""
+    float32 bytes) and crop / flip / normalise / cast run as one kernel on the GPU. ``resize``: a ``datasets.DeviceResize``
+    when the workers only decode (``raw="decoded"`` + ``ragged_collate``): the batch arrives as (flat bytes, sizes, ...)."""
     for batch in loader:
+        if resize is not None:
+            inputs = resize(batch[0], batch[1])
+            batch = (inputs,) + tuple(batch[2:])
         inputs, targets, weights = batch[0], batch[1], batch[2]
         inputs = inputs.to(device, non_blocking=True)
         if augment is not None:
@@ -299,7 +305,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
         df_train, df_val, df_test = df[df['split'] == 'train'], df[df['split'] == 'val'], df[df['split'] == 'test']
         train_labels = df_train['age']
         cls = datasets.IMDBWIKI if args.dataset == 'imdb_wiki' else datasets.AgeDB
-        raw = bool(args.gpu_augment)
+        raw = "decoded" if args.gpu_resize else bool(args.gpu_augment)
         train_set = cls(data_dir=args.data_dir, df=df_train, img_size=args.img_size, split='train', reweight=args.reweight,
                         lds=args.lds, lds_kernel=args.lds_kernel, lds_ks=args.lds_ks, lds_sigma=args.lds_sigma, raw=raw)
         val_set = cls(data_dir=args.data_dir, df=df_val, img_size=args.img_size, split='val', raw=raw)
@@ -308,16 +314,18 @@ def run(argv=None, dataset_default='imdb_wiki'):
         aug_dtype = torch.bfloat16 if args.amp == 'bf16' else torch.float32
         aug_train = datasets.DeviceAugment(args.img_size, train=True, dtype=aug_dtype) if raw else None
         aug_eval = datasets.DeviceAugment(args.img_size, train=False, dtype=aug_dtype) if raw else None
+        dev_resize = datasets.DeviceResize(args.img_size, device) if args.gpu_resize else None
+        collate = datasets.ragged_collate if args.gpu_resize else None
 
         def train_batches(epoch):
             idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
             loader = DataLoader(_ShardSubset(train_set, idx.tolist(), valid.tolist()), batch_size=args.batch_size, shuffle=True,
-                                num_workers=args.workers, pin_memory=True, drop_last=False)
-            return lambda: _loader_batches(loader, device, aug_train)
+                                num_workers=args.workers, pin_memory=True, drop_last=False, collate_fn=collate)
+            return lambda: _loader_batches(loader, device, aug_train, dev_resize)
 
         def eval_batches(ds):
-            loader = DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, pin_memory=True)
-            return lambda: _loader_batches(loader, device, aug_eval)
+            loader = DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, pin_memory=True, collate_fn=collate)
+            return lambda: _loader_batches(loader, device, aug_eval, dev_resize)
         steps_per_epoch = (len(shard_indices(n_train, rank, world)) + args.batch_size - 1) // args.batch_size
         n_val = (len(val_set) + args.batch_size - 1) // args.batch_size
     print(f"Training data size: {len(train_set)}")

@@ -417,6 +417,18 @@ int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float*
  * no flip); out [B, S, S, 3] float32 or bf16 (dtype) = a channels_last [B, 3, S, S] tensor, float32 arithmetic exactly as
  * ToTensor / Normalize execute it ((u8 / 255 - 0.5) / 0.5; padding pixels -> -1). */
 int dir_augment_u8(const void* img, const int* params, void* out, int dtype, int B, int S, int pad, dir_stream_t stream);
+/* The Resize((S, S)) in front of that chain (imdb-wiki-dir/datasets.py:41,49: torchvision Resize on a PIL image = Pillow's bilinear
+ * resize, antialiased when shrinking) for a RAGGED batch of decoded uint8 RGB images, bit for bit Pillow's result (fixed-point
+ * two-pass algorithm of Pillow's Resample.c; oracle/resize_oracle.py): loader workers only decode.
+ *   src: device bytes holding the B images back to back (HWC, 3 channels); table [B][4] int64 (device) = (byte offset of image b in
+ *   src, H_b, W_b, byte offset of its [H_b][S][3] intermediate inside the workspace's tmp area); out [B, S, S, 3] uint8 — the input of
+ *   dir_augment_u8.  hmax = max H_b; kmax = max over images and axes of dir_resize_ksize(in, S) (taps of the widest window);
+ *   workspace >= dir_resize_u8_workspace(B, S, kmax, tmp_bytes), tmp_bytes = end of the last intermediate (sum of H_b * S * 3, offsets
+ *   chosen by the host).  Three launches, no host sync. */
+int    dir_resize_ksize(int in_size, int out_size);
+size_t dir_resize_u8_workspace(int B, int S, int kmax, size_t tmp_bytes);
+int    dir_resize_u8(const void* src, const long long* table, void* out, int B, int S, int hmax, int kmax, void* workspace,
+                     size_t workspace_bytes, dir_stream_t stream);
 
 
 
