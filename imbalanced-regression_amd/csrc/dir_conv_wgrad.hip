@@ -294,6 +294,166 @@ conv_wgrad_kernel(WgP p) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 / stride-1 weight gradient, register-lean form (round 4): dW[co][ci] = sum_m dY[m][co] * X[m][ci] with both operands staged in
+// LDS in their NATURAL [pixel][channel] layout by LDS-DMA (buffer_load ... lds, no staging registers, no v_perm, no ds_write pass)
+// and the MFMA fragments — 8 consecutive pixels (the K axis) of one channel per lane — read with the hardware-transposing
+// ds_read_b64_tr_b16 (two per operand and 16-pixel step), as the all-taps 3x3 kernel does (dir_conv_wgrad3.hip). The transposing
+// kernel above needs 248 registers (two workgroups per CU) and every removed phase left its 1x1 launches on 14^2 / 7^2 maps at ~45 us:
+// 24 K-steps x a barrier that two wavefronts per SIMD cannot hide (profiles/r03_small_kernel_experiments.txt). This one holds 64
+// accumulators + 16 fragment registers + a dozen addresses: <= 128 registers, one 32 KB stage (NST = 1: FOUR workgroups per CU, whose
+// phases overlap each other) or two stages (NST = 2: two per CU, the next K-step's DMA in flight during the MFMAs).
+// Tile 128 (co) x 128 (ci), 2 x 2 wavefronts of 64 x 64; K-step = 64 pixels; LDS rows of 256 B (128 channels), the 64-byte quarter
+// of a row XORed with (pixel & 3) — on the DMA's SOURCE side, the destination is lane-linear — so that the four rows of a
+// transposing read fall into four different 16-bank groups.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) __bf16 wg_bf16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t wg_u32x4;
+__device__ __forceinline__ wg_bf16x4 wg_tr(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) wg_bf16x4* lds_v4_t;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)p);
+}
+__device__ __forceinline__ bf16x8 wg_cat(wg_bf16x4 a, wg_bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ wg_u32x4 wg_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    wg_u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return r;
+}
+// one LDS-DMA piece: 64 lanes x 16 B -> 1 KB at lds_addr (wave-uniform), sources voffset (per lane) + soffset (wave-uniform).
+// Inline assembly on purpose: the compiler would otherwise drain the DMA (s_waitcnt vmcnt(0)) in front of every LDS read it cannot
+// prove disjoint from it.
+__device__ __forceinline__ void wg_dma16(wg_u32x4 rs, uint32_t lds_addr, int voffset, int soffset) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
+}
+
+constexpr int W1_T = 128, W1_ROWB = W1_T * 2, W1_OP = WG_BK * W1_ROWB, W1_STAGE = 2 * W1_OP;      // 256-B rows, 16 KB per operand, 32 KB per stage
+
+template <int NST>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(NST == 1 ? 4 : 2)))
+conv_wgrad1_dma_kernel(WgP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b;
+    {
+        const int nb = gridDim.x, id = blockIdx.x, q = nb / 8, r = nb % 8, xcd = id % 8, i = id / 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int tn = b % p.tiles_n; b /= p.tiles_n;
+    const int tm = b % p.tiles_m; b /= p.tiles_m;
+    const int split = b;
+    const int co0 = tm * W1_T, ci0 = tn * W1_T;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int ks0 = split * p.ksteps_per_split;
+    int ks1 = ks0 + p.ksteps_per_split; if (ks1 > p.ksteps_total) ks1 = p.ksteps_total;
+
+    // ---- DMA roles: wavefront w stages rows 16 w .. 16 w + 15 of both operands, 4 pieces of 4 rows each; lane l of a piece lands at
+    // row (l >> 4), 16-byte chunk (l & 15) and fetches the chunk whose 64-byte quarter is XORed with the row's low two bits
+    const wg_u32x4 rs_dy = wg_rsrc(p.dy, (uint32_t)p.M * (uint32_t)p.Cout * 2u), rs_x = wg_rsrc(p.x, (uint32_t)p.M * (uint32_t)p.Cin * 2u);
+    const int lrow = 16 * wave + (lane >> 4);                                  // + 4 j for piece j
+    const int lchunk = (lane & 15) ^ (((lane >> 4) & 3) << 2);                 // (row & 3) == (lane >> 4) & 3: 16 w + 4 j are multiples of 4
+    const int vo_a = (lrow * p.Cout + co0) * 2 + lchunk * 16, vo_b = (lrow * p.Cin + ci0) * 2 + lchunk * 16;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;                            // (LDS addresses are 32-bit offsets)
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)(16 * wave) * W1_ROWB)), lb = la + W1_OP;   // wave-uniform: SGPRs (M0)
+    const int rowa4 = 4 * p.Cout * 2, rowb4 = 4 * p.Cin * 2;                   // four rows further (the next piece)
+
+    // ---- fragment reads: within a 16-lane group, lane i addresses pixel row (i >> 2), channels 4 (i & 3) .. + 3 of the group's 16
+    // channels and receives channel i, four consecutive pixels; groups 0 / 1 = channels 0-15 / 16-31 of the 32-wide MFMA tile,
+    // groups 2 / 3 the same for pixels 8-15 of the 16-pixel step
+    const int gi = lane & 15, grp = lane >> 4;
+    const int prow = (grp >> 1) * 8 + (gi >> 2);                               // + 4 h + 16 kk as instruction immediates
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ca = wm * 64 + i * 32 + (grp & 1) * 16 + 4 * (gi & 3), cb = wn * 64 + i * 32 + (grp & 1) * 16 + 4 * (gi & 3);
+        fa[i] = (uint32_t)(prow * W1_ROWB + ((ca * 2) ^ ((prow & 3) << 6)));
+        fb[i] = (uint32_t)(W1_OP + prow * W1_ROWB + ((cb * 2) ^ ((prow & 3) << 6)));
+        asm volatile("" : "+v"(fa[i])); asm volatile("" : "+v"(fb[i]));
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+#define W1_ISSUE(ks, stage)                                                                                               \
+    {                                                                                                                     \
+        const int mrem = p.M - (ks) * WG_BK;                      /* rows left from this K-step's first row (> 0) */      \
+        const int soa = (ks) * WG_BK * p.Cout * 2, sob = (ks) * WG_BK * p.Cin * 2;                                        \
+        _Pragma("unroll")                                                                                                 \
+        for (int j = 0; j < 4; ++j) {                                                                                     \
+            const bool ok = lrow + 4 * j < mrem;                  /* rows past M: out of range -> zeros, no access */     \
+            wg_dma16(rs_dy, la + (stage) * W1_STAGE + j * 4 * W1_ROWB, ok ? vo_a + j * rowa4 : WG_OOB, soa);              \
+            wg_dma16(rs_x, lb + (stage) * W1_STAGE + j * 4 * W1_ROWB, ok ? vo_b + j * rowb4 : WG_OOB, sob);               \
+        }                                                                                                                 \
+    }
+#define W1_MFMA(stage)                                                                                                    \
+    {                                                                                                                     \
+        const unsigned char* sb = smem + (stage) * W1_STAGE;                                                              \
+        _Pragma("unroll")                                                                                                 \
+        for (int kk = 0; kk < 4; ++kk) {                                                                                  \
+            bf16x8 a[2], bb[2];                                                                                           \
+            _Pragma("unroll")                                                                                             \
+            for (int i = 0; i < 2; ++i) {                                                                                 \
+                a[i] = wg_cat(wg_tr(sb + fa[i] + kk * 16 * W1_ROWB), wg_tr(sb + fa[i] + kk * 16 * W1_ROWB + 4 * W1_ROWB)); \
+                bb[i] = wg_cat(wg_tr(sb + fb[i] + kk * 16 * W1_ROWB), wg_tr(sb + fb[i] + kk * 16 * W1_ROWB + 4 * W1_ROWB)); \
+            }                                                                                                             \
+            _Pragma("unroll")                                                                                             \
+            for (int mi = 0; mi < 2; ++mi)                                                                                \
+                _Pragma("unroll")                                                                                         \
+                for (int ni = 0; ni < 2; ++ni)                                                                            \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);           \
+        }                                                                                                                 \
+    }
+    if constexpr (NST == 1) {
+        for (int ks = ks0; ks < ks1; ++ks) {
+            W1_ISSUE(ks, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                      // everyone's pieces have landed
+            W1_MFMA(0);
+            __syncthreads();                                      // everyone is done reading the stage
+        }
+    } else {
+        if (ks0 < ks1) {
+            W1_ISSUE(ks0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int ks = ks0;
+            for (; ks + 2 <= ks1; ks += 2) {                      // stages are literals: two K-steps per trip
+                W1_ISSUE(ks + 1, 1);                              // lands during this step's MFMAs
+                W1_MFMA(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (ks + 2 < ks1) W1_ISSUE(ks + 2, 0);
+                W1_MFMA(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (ks < ks1) W1_MFMA(0);                             // odd count: the last tile sits in stage 0
+        }
+    }
+#undef W1_ISSUE
+#undef W1_MFMA
+
+    // partial[split][co][ci] (fp32). C/D: col = lane & 31 -> ci, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -> co (as conv_wgrad_kernel)
+    const int rsc = p.Cin;
+    float* out = p.part + (size_t)split * p.Cout * rsc + (size_t)co0 * rsc + ci0;
+    const uint32_t toff = (uint32_t)((wm * 64 + 4 * fhalf) * rsc + wn * 64 + frow);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float* ob = out + (size_t)(mi * 32 + (e & 3) + 8 * (e >> 2)) * rsc + ni * 32;
+                ob[toff] = acc[mi][ni][e];
+            }
+}
+
 // Sum the split partials in split order. 256 threads = 16 float4 columns x 16 split lanes: lane j adds splits
 // j, j+16, ... (independent loads in flight), then the 16 lane sums are added in lane order through LDS —
 // a fixed summation tree, so the result is bit-reproducible, and a 1024-way split costs 64 loads per thread
@@ -322,10 +482,14 @@ conv_wgrad_reduce_kernel(const float* __restrict__ part, int splits, size_t n, f
     }
 }
 
-struct WgPlan { int tm, tn, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split; size_t ws_bytes; };
+struct WgPlan { int tm, tn, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split; size_t ws_bytes; int dma1; };
 
-WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
+// dma1: the register-lean 1x1 form (conv_wgrad1_dma_kernel): 0 = the transposing kernel, 1 = one stage / four workgroups per CU,
+// 2 = two stages / two per CU. W1_FORM is the product's choice for the 1x1 / stride-1 layers with 128-multiples of channels.
+constexpr int W1_FORM = 2;
+WgPlan wg_plan(long long M, int Cin, int Cout, int RS, int dma1 = 0) {
     WgPlan pl;
+    pl.dma1 = dma1;
     pl.tm = (Cout % 128 == 0) ? 128 : 64;
     pl.tn = (Cin % 128 == 0) ? 128 : 64;
     pl.tiles_m = Cout / pl.tm; pl.tiles_n = Cin / pl.tn;
@@ -335,7 +499,7 @@ WgPlan wg_plan(long long M, int Cin, int Cout, int RS) {
     // for the 128x128 tile, 3 otherwise: registers / LDS), and a grid slightly above a multiple of that costs a whole
     // extra round. One round measured best (4.99 -> 4.40 ms per ResNet-50 step at batch 256), unless that leaves fewer than
     // 4 K ranges per tile (512-channel 3x3 layers): then two.
-    const int slots = 256 * ((pl.tm == 128 && pl.tn == 128) ? 2 : 3);
+    const int slots = 256 * (dma1 == 1 ? 4 : (pl.tm == 128 && pl.tn == 128) ? 2 : 3);
     const int rounds = slots / tiles >= 4 ? 1 : 2;
     int splits = rounds * slots / tiles;
     int max_splits = pl.ksteps_total / 4; if (max_splits < 1) max_splits = 1;      // >= 4 K-steps per workgroup
@@ -364,17 +528,30 @@ extern "C" int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_
     return DIR_OK;
 }
 
-extern "C" size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
+// form (DIR_WGRAD_*): 0 = the product's choice, 1 = the transposing kernel, 2 / 3 = the LDS-DMA + transposing-read 1x1 kernel with one /
+// two stages. Returns the plan's dma1 code, or -1 when the forced form does not take the geometry.
+static int wg_dma1_form(int Cin, int Cout, int R, int S, int stride, int pad, int form) {
+    const bool ok = R == 1 && S == 1 && stride == 1 && pad == 0 && Cin % 128 == 0 && Cout % 128 == 0;
+    if (form == DIR_WGRAD_AUTO) return ok ? W1_FORM : 0;
+    if (form == DIR_WGRAD_TRANSPOSE) return 0;
+    if (form == DIR_WGRAD_DMA1 || form == DIR_WGRAD_DMA2) return ok ? form - 1 : -1;
+    return -1;
+}
+
+extern "C" size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int form) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
-    return wg_plan((long long)N * Ho * Wo, Cin, Cout, R * S).ws_bytes;
+    const int dma1 = wg_dma1_form(Cin, Cout, R, S, stride, pad, form);
+    if (dma1 < 0) return 0;
+    return wg_plan((long long)N * Ho * Wo, Cin, Cout, R * S, dma1).ws_bytes;
 }
 
 extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                              int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
+                              int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
                               dir_stream_t stream) {
     DIR_RETURN_IF(!dy || !x || !dw || !workspace, DIR_EINVAL);
+    DIR_RETURN_IF(form < DIR_WGRAD_AUTO || form > DIR_WGRAD_DMA2, DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % 64 != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
     DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || !dir_aligned16(dw) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
@@ -382,7 +559,9 @@ extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     const long long M = (long long)N * Ho * Wo;
     DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 30), DIR_EUNSUPPORTED);   // 32-bit byte offsets
-    const WgPlan pl = wg_plan(M, Cin, Cout, R * S);
+    const int dma1 = wg_dma1_form(Cin, Cout, R, S, stride, pad, form);
+    DIR_RETURN_IF(dma1 < 0, DIR_EUNSUPPORTED);
+    const WgPlan pl = wg_plan(M, Cin, Cout, R * S, dma1);
     DIR_RETURN_IF(workspace_bytes < pl.ws_bytes, DIR_EWORKSPACE);
     WgP p;
     p.dy = static_cast<const uint16_t*>(dy); p.x = static_cast<const uint16_t*>(x); p.part = static_cast<float*>(workspace);
@@ -402,7 +581,12 @@ extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
     }
     const int nblocks = pl.splits * pl.tiles_m * pl.tiles_n * p.RS;
     hipStream_t s = dir_s(stream);
-    if (pl.tm == 128 && pl.tn == 128) wg_launch<128, 128>(p, nblocks, s);
+    if (pl.dma1 == 1) hipLaunchKernelGGL(conv_wgrad1_dma_kernel<1>, dim3(nblocks), dim3(DIR_TPB), W1_STAGE, s, p);
+    else if (pl.dma1 == 2) {
+        DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad1_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W1_STAGE));
+        hipLaunchKernelGGL(conv_wgrad1_dma_kernel<2>, dim3(nblocks), dim3(DIR_TPB), 2 * W1_STAGE, s, p);
+    }
+    else if (pl.tm == 128 && pl.tn == 128) wg_launch<128, 128>(p, nblocks, s);
     else if (pl.tm == 128) wg_launch<128, 64>(p, nblocks, s);
     else if (pl.tn == 128) wg_launch<64, 128>(p, nblocks, s);
     else wg_launch<64, 64>(p, nblocks, s);

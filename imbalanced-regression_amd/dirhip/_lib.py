@@ -81,9 +81,8 @@ SIGNATURES = {
     "dir_conv_dgrad_join": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "dir_conv_fwd": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dir_conv_fwd_variant": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
-    "dir_conv_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "dir_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_conv_wgrad_workspace": (c_size_t, [c_int] * 10),
+    "dir_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad3x3_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad_reduce_splits": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
@@ -125,6 +124,7 @@ SIGNATURES = {
 
 ABI_VERSION = 2
 DIR_F32, DIR_BF16 = 0, 1
+WGRAD_AUTO, WGRAD_TRANSPOSE, WGRAD_DMA1, WGRAD_DMA2 = 0, 1, 2, 3                             # DIR_WGRAD_*
 CONV_AUTO, CONV_TILE_REG, CONV_TILE_DMA, CONV_PATCH3, CONV_BIG = 0, 1, 2, 3, 5      # DIR_CONV_* of include/dir_hip.h
 FLAG_HAS_LO, FLAG_HAS_HI, FLAG_NONINTEGER, FLAG_NAN = 1, 2, 4, 8
 FACTOR_ZERO, FACTOR_MOMENTUM, FACTOR_COUNT = 0, 1, 2

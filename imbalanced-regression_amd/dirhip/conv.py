@@ -183,9 +183,10 @@ def _wgrad_side_done(device, side, *operands):
         _WGRAD_SIDE["task"] = task
 
 
-def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None):
+def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None, form=L.WGRAD_AUTO):
     """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``. ``sink``: the
-    parameter's gradient-bucket factory (``gradsink.lookup``): the kernel then writes into the data-parallel bucket."""
+    parameter's gradient-bucket factory (``gradsink.lookup``): the kernel then writes into the data-parallel bucket. ``form``:
+    ``L.WGRAD_*`` (``DIR_WGRAD_*``) — the kernel form of THIS launch for the per-tap path; 0 = the product's choice."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
     if not dy.is_contiguous(memory_format=torch.channels_last):
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -195,15 +196,15 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None):
     dw = gradsink.out_for(sink, (cout, cin, kernel_size, kernel_size), x.device, torch.channels_last)
     side = _wgrad_side(x.device)
     if side is None:
-        _wgrad_launch(dy, x, dw, kernel_size, stride, padding)
+        _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form)
     else:
         with torch.cuda.stream(side):
-            _wgrad_launch(dy, x, dw, kernel_size, stride, padding)
+            _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form)
         _wgrad_side_done(x.device, side, dy, x)
     return dw
 
 
-def _wgrad_launch(dy, x, dw, kernel_size, stride, padding):
+def _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form=L.WGRAD_AUTO):
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     r = s = kernel_size
@@ -214,11 +215,11 @@ def _wgrad_launch(dy, x, dw, kernel_size, stride, padding):
             L.check(L.lib().dir_conv_wgrad3x3(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
                                               L.stream_ptr(x.device)), "dir_conv_wgrad3x3")
             return
-    nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding)
+    nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding, form)
     if nbytes == 0:
-        raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout}")
+        raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout} (form {form})")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, L.ptr(ws),
+    L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, form, L.ptr(ws),
                                    ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
 
 

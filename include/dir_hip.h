@@ -394,9 +394,14 @@ int dir_conv_fwd_variant(const void* x, const void* w, void* y, float* stats, in
  * `workspace` (>= dir_conv_wgrad_workspace(...) bytes, 256-byte aligned; 0 = unsupported shape).
  * Replaces the weight half of nn.Conv2d's autograd (imdb-wiki-dir/resnet.py conv layers with Cin, Cout % 64 == 0).
  */
-size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+/* form (per launch, like `variant` of the forward entry points): DIR_WGRAD_AUTO = the product's choice — the 1x1 / stride-1 layers with
+ * 128-multiples of channels take the register-lean form (both operands staged by LDS-DMA in their natural [pixel][channel] layout,
+ * MFMA fragments by the transposing LDS read ds_read_b64_tr_b16: <= 128 registers, four workgroups per CU), everything else the
+ * transposing kernel; the other values force one form (tests, A/B): DIR_EUNSUPPORTED / workspace 0 when it does not take the geometry. */
+enum { DIR_WGRAD_AUTO = 0, DIR_WGRAD_TRANSPOSE = 1, DIR_WGRAD_DMA1 = 2 /* one LDS stage, four workgroups per CU */, DIR_WGRAD_DMA2 = 3 /* two stages */ };
+size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int form);
 int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                   int R, int S, int stride, int pad, void* workspace, size_t workspace_bytes,
+                   int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
                    dir_stream_t stream);
 /* The 3x3 / stride-1 / pad-1 weight gradients (conv2 of every Bottleneck but the three strided ones, resnet.py:46-47) in ONE
  * pass over dY and X for all nine taps: H == W in {56, 28, 14, 7}, Cin % 64 == 0, Cout % 64 == 0 (workspace 0 = not this

@@ -75,10 +75,10 @@ for ci, co, h in SH:
     xs = [torch.randn(B, ci, h, h, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
     dys = [torch.randn(B, co, h, h, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
     dw = torch.empty(co, ci, device=dev)
-    nws = lib.dir_conv_wgrad_workspace(B, h, h, ci, co, 1, 1, 1, 0)
+    nws = lib.dir_conv_wgrad_workspace(B, h, h, ci, co, 1, 1, 1, 0, 1)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     def run(i):
-        L.check(lib.dir_conv_wgrad(L.ptr(dys[i % nbuf]), L.ptr(xs[i % nbuf]), L.ptr(dw), B, h, h, ci, co, 1, 1, 1, 0, L.ptr(ws), nws, L.stream_ptr(dev)), "wgrad")
+        L.check(lib.dir_conv_wgrad(L.ptr(dys[i % nbuf]), L.ptr(xs[i % nbuf]), L.ptr(dw), B, h, h, ci, co, 1, 1, 1, 0, 1, L.ptr(ws), nws, L.stream_ptr(dev)), "wgrad")
     for i in range(3): run(i)
     best = 1e9
     for r in range(3):
