@@ -1394,20 +1394,38 @@ __device__ __forceinline__ float adam_update(float p, float g, float* __restrict
     return p - h.step_size * (m1 / denom);                                        // param.addcdiv_(exp_avg, denom, value=-step_size), step_size = lr / bias_correction1
 }
 
-// ADAM: w is first UPDATED in place from (g, m, v) — the optimizer step — and the bf16 operands are made from the new value in the
+// torch.optim.SGD's single-tensor arithmetic (sgd.py: _single_tensor_sgd), one element; returns the new parameter value. The `add(x, alpha=a)`
+// steps are written as fmaf, which is how torch's element-wise kernels evaluate `a + alpha * b`.
+struct SgdH { float lr, momentum, one_minus_dampening, weight_decay; int nesterov, first; };
+__device__ __forceinline__ float sgd_update(float p, float g, float* __restrict__ buf, size_t i, const SgdH& h) {
+    if (h.weight_decay != 0.0f) g = __fmaf_rn(h.weight_decay, p, g);                 // grad = grad.add(param, alpha=weight_decay)
+    if (h.momentum != 0.0f) {
+        const float b = h.first ? g : __fmaf_rn(h.one_minus_dampening, g, buf[i] * h.momentum);   // buf = clone(grad) | buf.mul_(momentum).add_(grad, alpha=1 - dampening)
+        buf[i] = b;
+        g = h.nesterov ? __fmaf_rn(h.momentum, b, g) : b;                             // grad = grad.add(buf, alpha=momentum) | buf
+    }
+    return __fmaf_rn(-h.lr, g, p);                                                    // param.add_(grad, alpha=-lr)
+}
+// what the weight preparation pass does to the master weight first: nothing, an Adam step, an SGD step
+struct OptNone { __device__ __forceinline__ float operator()(float w, size_t) const { return w; } static constexpr bool UPDATES = false; };
+struct OptAdam { const float* g; float* m; float* v; AdamH h; static constexpr bool UPDATES = true;
+                 __device__ __forceinline__ float operator()(float w, size_t i) const { return adam_update(w, g[i], m, v, i, h); } };
+struct OptSgd { const float* g; float* buf; SgdH h; static constexpr bool UPDATES = true;
+                __device__ __forceinline__ float operator()(float w, size_t i) const { return sgd_update(w, g[i], buf, i, h); } };
+
+// OPT::UPDATES: w is first UPDATED in place from (g, m, v) — the optimizer step — and the bf16 operands are made from the new value in the
 // same pass (dir_adam_step): one read of the master weight for the optimizer and the two layout conversions together.
-template <bool ADAM = false>
+template <typename OPT = OptNone>
 __device__ __forceinline__ void conv_prep_body(float* __restrict__ w, int Cout, int RS, int Cin,
                                                uint16_t* __restrict__ w16, uint16_t* __restrict__ w16_rot, int rot_mode,
-                                               const float* __restrict__ g = nullptr, float* __restrict__ m = nullptr,
-                                               float* __restrict__ v = nullptr, AdamH h = AdamH{}) {
+                                               const OPT opt = OPT{}) {
     __shared__ uint16_t tile[64][66];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;           // 4 rows of 64 per pass
     if ((Cout & 63) || (Cin & 63)) {                               // generic fallback (not used by ResNet-50's layers)
         const size_t n = (size_t)Cout * RS * Cin;
         for (size_t i = (size_t)blockIdx.x * DIR_TPB + t; i < n; i += (size_t)gridDim.x * DIR_TPB) {
             float wv = w[i];
-            if (ADAM) { wv = adam_update(wv, g[i], m, v, i, h); w[i] = wv; }
+            if (OPT::UPDATES) { wv = opt(wv, i); w[i] = wv; }
             const uint16_t h = (uint16_t)cv_f2bf(wv);
             w16[i] = h;
             if (w16_rot) {
@@ -1424,7 +1442,7 @@ __device__ __forceinline__ void conv_prep_body(float* __restrict__ w, int Cout, 
         for (int r = ty; r < 64; r += 4) {                         // row = output channel, 64 consecutive input channels
             const size_t i = ((size_t)(co0 + r) * RS + tap) * Cin + ci0 + tx;
             float wv = w[i];
-            if (ADAM) { wv = adam_update(wv, g[i], m, v, i, h); w[i] = wv; }
+            if (OPT::UPDATES) { wv = opt(wv, i); w[i] = wv; }
             const uint16_t hb = (uint16_t)cv_f2bf(wv);
             w16[i] = hb;
             tile[r][tx] = hb;
@@ -1466,14 +1484,45 @@ adam_step_kernel(const long long* __restrict__ table, AdamH h) {
     float* m = reinterpret_cast<float*>(e[2]);
     float* v = reinterpret_cast<float*>(e[3]);
     if (e[5]) {
-        conv_prep_body<true>(w, (int)e[7], (int)e[8], (int)e[9], reinterpret_cast<uint16_t*>(e[5]), reinterpret_cast<uint16_t*>(e[6]), (int)e[10], g, m, v, h);
+        conv_prep_body<OptAdam>(w, (int)e[7], (int)e[8], (int)e[9], reinterpret_cast<uint16_t*>(e[5]), reinterpret_cast<uint16_t*>(e[6]), (int)e[10], OptAdam{g, m, v, h});
         return;
     }
     const size_t n = (size_t)e[4];
     for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * DIR_TPB)
         w[i] = adam_update(w[i], g[i], m, v, i, h);
 }
+
+// The same launch shape for torch.optim.SGD (rows: param, grad, momentum_buffer (0 = no momentum), 0, numel, w16, w16_rot, Cout, RS, Cin, rot_mode, 0)
+__global__ void __launch_bounds__(DIR_TPB)
+sgd_step_kernel(const long long* __restrict__ table, SgdH h) {
+    const long long* e = table + (size_t)blockIdx.y * 12;
+    float* w = reinterpret_cast<float*>(e[0]);
+    const float* g = reinterpret_cast<const float*>(e[1]);
+    float* buf = reinterpret_cast<float*>(e[2]);
+    if (e[5]) {
+        conv_prep_body<OptSgd>(w, (int)e[7], (int)e[8], (int)e[9], reinterpret_cast<uint16_t*>(e[5]), reinterpret_cast<uint16_t*>(e[6]), (int)e[10], OptSgd{g, buf, h});
+        return;
+    }
+    const size_t n = (size_t)e[4];
+    for (size_t i = (size_t)blockIdx.x * DIR_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * DIR_TPB)
+        w[i] = sgd_update(w[i], g[i], buf, i, h);
+}
 }  // namespace
+
+// torch.optim.SGD.step() (train.py:163-164 builds it for --optimizer sgd) for all parameters in ONE launch, fused with the bf16 weight
+// preparation like dir_adam_step. table: device [ntensors][12] int64 (see sgd_step_kernel). first != 0: the momentum buffers do not
+// hold a value yet (torch creates them as clone(grad) at the first step); momentum == 0: no buffer is touched (entries may be 0).
+extern "C" int dir_sgd_step(const void* table, int ntensors, double lr, double momentum, double dampening, double weight_decay, int nesterov,
+                            int first, dir_stream_t stream) {
+    DIR_RETURN_IF(!table || ntensors <= 0 || ntensors > 65535, DIR_EINVAL);
+    DIR_RETURN_IF(nesterov && (momentum <= 0.0 || dampening != 0.0), DIR_EINVAL);       // torch: "Nesterov momentum requires a momentum and zero dampening"
+    SgdH h;
+    h.lr = (float)lr; h.momentum = (float)momentum; h.one_minus_dampening = (float)(1.0 - dampening); h.weight_decay = (float)weight_decay;
+    h.nesterov = nesterov ? 1 : 0; h.first = first ? 1 : 0;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(128, ntensors), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const long long*>(table), h);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
 
 // torch.optim.Adam.step() (train.py:161-162 builds the optimizer, :259-260 steps it) for all parameters in ONE launch, fused with
 // the bf16 weight preparation of the convolution layers (dir_conv_prep_weights_batched). table: device [ntensors][12] int64 (see

@@ -68,6 +68,7 @@ SIGNATURES = {
     "dir_bn_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "dir_conv_stats_rows": (c_size_t, [c_int, c_int, c_int]),
     "dir_adam_step": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_longlong, c_void_p]),
+    "dir_sgd_step": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     "dir_conv_prep_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_conv_prep_weights_batched": (c_int, [c_void_p, c_int, c_void_p]),
     "dir_conv_prep_weights_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -114,3 +114,99 @@ class Adam(torch.optim.Adam):
                                           float(group["weight_decay"]), step, L.stream_ptr(dev)), "dir_adam_step")
             _conv.mark_prepared_after_step([pw for pw in cached[2] if pw is not None])
         return loss
+
+
+class SGD(torch.optim.SGD):
+    """Drop-in for the ``torch.optim.SGD`` of ``imdb-wiki-dir/train.py:163-164`` (``--optimizer sgd``: lr, momentum, weight decay; same
+    ``state_dict`` layout: ``momentum_buffer`` per parameter). ``step()`` = ONE HIP launch for all parameter tensors (``dir_sgd_step``:
+    torch's single-tensor SGD arithmetic) that also rewrites the bf16 operands of the convolution weights — as ``Adam`` above. What the
+    kernel does not take (maximize, differentiable, CPU / non-float32 / non-dense parameters, parameters of one group in different
+    momentum-buffer states) goes to ``torch.optim.SGD``'s own step."""
+
+    def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False, **kw):
+        kw.pop("fused", None)
+        kw.pop("foreach", None)
+        super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov, foreach=False, fused=False, **kw)
+        self._tables = {}
+
+    def _ours(self, group, params):
+        if group.get("maximize") or group.get("differentiable") or isinstance(group["lr"], torch.Tensor):
+            return False
+        dev = params[0].device
+        have = None
+        for p in params:
+            g = p.grad
+            if not (p.is_cuda and p.device == dev and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse):
+                return False
+            if p.stride() != g.stride() or not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                return False
+            buf = self.state.get(p, {}).get("momentum_buffer")
+            if have is None:
+                have = buf is not None
+            elif have != (buf is not None):
+                return False                                                # mixed first / later steps inside one group: torch's loop handles it
+            if buf is not None:
+                if not (buf.dtype == torch.float32 and buf.device == dev and buf.shape == p.shape):
+                    return False
+                if buf.stride() != p.stride():                              # e.g. a reference checkpoint's NCHW buffers next to channels_last parameters
+                    self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(buf)
+        return True
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_tables"):
+            self._tables = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if params and not self._ours(group, params):
+                super().step(None)                                          # torch's own step for every group (never a mix)
+                return loss
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            mom = float(group["momentum"])
+            first = 0
+            if mom != 0.0:
+                first = int(self.state[params[0]].get("momentum_buffer") is None)
+                if first:
+                    for p in params:
+                        self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)   # filled by the kernel (= clone(grad))
+            dev = params[0].device
+            bufs = [self.state[p]["momentum_buffer"] if mom != 0.0 else None for p in params]
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), 0 if b is None else b.data_ptr()) for p, b in zip(params, bufs))
+            cached = self._tables.get(gi)
+            if cached is None or cached[0] != key:
+                prepared = _conv.prepared_operands(dev)
+                rows = []
+                for p, b in zip(params, bufs):
+                    pw = prepared.get(p.data_ptr())
+                    if pw is not None and not p.is_contiguous(memory_format=torch.channels_last):
+                        pw = None
+                    head = [p.data_ptr(), p.grad.data_ptr(), 0 if b is None else b.data_ptr(), 0, p.numel()]
+                    if pw is None:
+                        rows.append(head + [0, 0, 0, 0, 0, 0, 0])
+                    else:
+                        cout, rs, cin = pw.shape
+                        rows.append(head + [pw.w16.data_ptr(), 0 if pw.w16_rot is None else pw.w16_rot.data_ptr(), cout, rs, cin, pw.rot_mode, 0])
+                cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), [prepared.get(p.data_ptr()) for p in params])
+                self._tables[gi] = cached
+            L.check(L.lib().dir_sgd_step(L.ptr(cached[1]), len(params), float(group["lr"]), mom, float(group["dampening"]), float(group["weight_decay"]),
+                                         int(bool(group["nesterov"])), first, L.stream_ptr(dev)), "dir_sgd_step")
+            _conv.mark_prepared_after_step([pw for pw in cached[2] if pw is not None])
+        return loss

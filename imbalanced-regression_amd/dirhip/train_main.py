@@ -26,7 +26,7 @@ from scipy.stats import gmean
 from .parallel import DataParallelEngine, init_distributed, shard_indices
 from .resnet import resnet50
 from .train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
-from .optim import Adam
+from .optim import SGD, Adam
 from .utils import AverageMeter, ProgressMeter, adjust_learning_rate, prepare_folders, save_checkpoint
 
 print = logging.info
@@ -360,7 +360,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
     if args.retrain_fc:
         assert 1 <= len(parameters) <= 2  # fc.weight, fc.bias
     optimizer = Adam(parameters, lr=args.lr) if args.optimizer == 'adam' else \
-        torch.optim.SGD(parameters, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+        SGD(parameters, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
 
     if args.pretrained:
         checkpoint = torch.load(args.pretrained, map_location="cpu")

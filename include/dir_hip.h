@@ -312,6 +312,12 @@ int dir_conv_prep_weights_batched(const void* table, int nlayers, dir_stream_t s
  * float64, like torch's non-capturable path).  Arithmetic = torch's single-tensor Adam (no amsgrad / maximize). */
 int dir_adam_step(const void* table, int ntensors, double lr, double beta1, double beta2, double eps, double weight_decay,
                   long long step, dir_stream_t stream);
+/* torch.optim.SGD.step() (imdb-wiki-dir/train.py:163-164: --optimizer sgd, momentum + weight decay) the same way: one launch for all
+ * parameter tensors + the bf16 operand preparation.  table rows: (param, grad, momentum_buffer or 0, 0, numel, w16, w16_rot, Cout, R*S, Cin,
+ * rot_mode, 0).  first != 0: the buffers hold no value yet (torch's first step sets them to the gradient).  Arithmetic = torch's
+ * single-tensor SGD (weight decay, momentum, dampening, nesterov; no maximize). */
+int dir_sgd_step(const void* table, int ntensors, double lr, double momentum, double dampening, double weight_decay, int nesterov, int first,
+                 dir_stream_t stream);
 /* rot_mode 0: as dir_conv_prep_weights.  rot_mode 1 (3x3): w16_rot receives the four parity-class weights of the
  * STRIDE-2 data gradient, packed back to back (class (a, b), a = row parity, b = column parity of the output pixel:
  * (1 + a)(1 + b) taps, [Cin][taps][Cout]; bases at 0, 1, 3, 5 taps x Cin x Cout) — the operand of dir_conv_dgrad_s2. */

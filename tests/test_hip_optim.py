@@ -158,3 +158,79 @@ def test_adam_loads_reference_layout_state_into_channels_last_model():
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
         assert torch.allclose(ours.state[a]["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
         assert torch.allclose(ours.state[a]["exp_avg_sq"], ref.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("momentum,weight_decay,nesterov,dampening", [(0.9, 1e-4, False, 0.0), (0.0, 0.0, False, 0.0), (0.9, 0.0, True, 0.0), (0.8, 1e-3, False, 0.1)])
+def test_sgd_matches_torch_single_tensor_sgd_and_rewrites_conv_operands(momentum, weight_decay, nesterov, dampening):
+    """dirhip.optim.SGD (--optimizer sgd of train.py:163-164) = ONE dir_sgd_step launch for all parameters: parameters and momentum buffers
+    against torch.optim.SGD(foreach=False) over three steps with fresh gradients each step, the state_dict layout, and the bf16 conv
+    operands the kernel rewrote (must equal dir_conv_prep_weights of the updated master weights, valid for the next forward)."""
+    from dirhip import _lib as L
+    from dirhip import conv as C
+    from dirhip.optim import SGD
+    model, eng, x = _model_with_grads()
+    ref_params = [p.detach().clone().requires_grad_(True) for p in model.parameters()]
+    kw = dict(lr=1e-2, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=dampening)
+    ours = SGD(model.parameters(), **kw)
+    theirs = torch.optim.SGD(ref_params, foreach=False, fused=False, **kw)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for step in range(3):
+        for rp, p in zip(ref_params, model.parameters()):
+            g = torch.randn(p.shape, device="cuda", generator=gen) * 0.1
+            if p.dim() == 4:
+                g = g.contiguous(memory_format=torch.channels_last)
+            p.grad.copy_(g)                                       # (the engine's persistent bucket slot)
+            rp.grad = g.clone(memory_format=torch.preserve_format)
+        theirs.step()
+        ours.step()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (n, p), rp in zip(model.named_parameters(), ref_params):
+        scale = max(rp.detach().abs().max().item(), 1e-12)
+        worst = max(worst, (p.detach().double() - rp.detach().double()).abs().max().item() / scale)
+        if momentum:
+            a, b = ours.state[p]["momentum_buffer"], theirs.state[rp]["momentum_buffer"]
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+        else:
+            assert "momentum_buffer" not in ours.state[p] or ours.state[p]["momentum_buffer"] is None
+    assert worst <= 1e-6, worst
+    sd_o, sd_t = ours.state_dict(), theirs.state_dict()
+    assert sd_o["param_groups"][0].keys() == sd_t["param_groups"][0].keys()
+    n_checked = 0
+    for m in model.modules():
+        st = getattr(m, "_dir_w16", None)
+        if st is None:
+            continue
+        w = m.weight.detach()
+        cout, rs, cin = st.shape
+        r = m.kernel_size[0]
+        w16 = torch.empty_like(st.w16)
+        rot = None if st.w16_rot is None else torch.empty_like(st.w16_rot)
+        L.check(L.lib().dir_conv_prep_weights_ex(L.ptr(w), cout, r, rs // r, cin, L.ptr(w16), L.ptr(rot), st.rot_mode, L.stream_ptr(w.device)), "prep")
+        assert torch.equal(w16.view(torch.int16), st.w16.view(torch.int16))
+        if rot is not None:
+            assert torch.equal(rot.view(torch.int16), st.w16_rot.view(torch.int16))
+        assert st.key == C._weight_key(m.weight)
+        n_checked += 1
+    assert n_checked >= 52
+    assert len(ours._tables) == 1
+
+
+def test_sgd_train_step_launches_no_library_optimizer_kernel():
+    from torch.profiler import ProfilerActivity, profile
+    from dirhip.loss import weighted_l1_loss
+    from dirhip.optim import SGD
+    from dirhip.train_loop import train_step
+    model, eng, x = _model_with_grads()
+    opt = SGD(eng.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    y = torch.full((8, 1), 30.0, device="cuda")
+    w = torch.ones(8, 1, device="cuda")
+    for _ in range(2):
+        train_step(eng, opt, x, y, w, 0, weighted_l1_loss, fds=False)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        train_step(eng, opt, x, y, w, 0, weighted_l1_loss, fds=False)
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert any("sgd_step_kernel" in n for n in names)
+    assert not any("multi_tensor" in n or "conv_prep_weights_batched" in n or "FusedSgd" in n for n in names), [n for n in names if "multi_tensor" in n or "prep" in n][:5]
+    assert len(opt._tables) == 1
