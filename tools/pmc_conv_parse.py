@@ -42,5 +42,5 @@ def parse(directory, batch=B):
 
 if __name__ == "__main__":
     res = parse(sys.argv[1])
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r02_conv_pmc_traffic.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r04_conv_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))

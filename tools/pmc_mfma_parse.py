@@ -1,6 +1,6 @@
 """MFMA utilisation of the conv_igemm kernels from a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`
 pass over tools/pmc_conv_pass.py (one launch pair per conv configuration of ResNet-50 at batch 256).
-    python tools/pmc_mfma_parse.py <counter_collection.csv>  ->  profiles/r02_conv_mfma_util.json
+    python tools/pmc_mfma_parse.py <counter_collection.csv> [name.json]  ->  profiles/r04_conv_mfma_util.json
 Utilisation per launch = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): the MFMA counter counts cycles, 32
 per v_mfma_f32_32x32x16_bf16, summed over all SIMDs (MI355X_MICROARCH.md; checked here: it equals FLOP / 32768 x 32 of the
 launch to 3 digits, `busy_over_ideal`), GRBM_GUI_ACTIVE is summed over the 8 XCDs (active / 8 / duration = 2.2 GHz, the
@@ -23,7 +23,7 @@ for cin, cout, k, st, h, cnt in RESNET50_CONVS:
     cfgs.append((f"{cin}->{cout} k{k} s{st} H{h} fwd", cnt, 2.0 * B * ho * ho * cout * cin * k * k))
     if st == 1:
         cfgs.append((f"{cout}->{cin} k{k} s1 H{ho} dgrad", cnt, 2.0 * B * ho * ho * cout * cin * k * k))
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_igemm" in r["Kernel_Name"] or "conv3x3_patch" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv_igemm" in r["Kernel_Name"] or "conv3x3_patch" in r["Kernel_Name"]]     # (conv_igemm_big_kernel included)
 by_disp = collections.OrderedDict()
 for r in rows:
     d = by_disp.setdefault(r["Dispatch_Id"], {"_t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
@@ -44,7 +44,7 @@ for (name, cnt, flop), d in zip(cfgs, disp[1::2]):                 # second laun
 out["weighted_mfma_util"] = tot_busy / (tot_active / 8.0 * 1024.0) if tot_active else None
 out["busy_over_ideal"] = tot_busy / tot_ideal
 out["note"] = "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace over tools/pmc_conv_pass.py 256"
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_conv_mfma_util.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r04_conv_mfma_util.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "layers"}, indent=1))
 for l in out["layers"]:
     u = l["mfma_util"]
