@@ -438,14 +438,20 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
             from dirhip.datasets import DeviceResize, ragged_collate
             ds = IMDBWIKI(df, tmp, img_size=224, split="train", raw=raw)
             n_img = 5000 * batch
+            # decode-only batches are ragged and 4x larger (file-size uint8: 78 MB per 256 images of 320 x 320): the loader's pinned pool would
+            # be workers x prefetch x 78 MB = 15 GB, whose allocation alone takes tens of seconds — that leg hands over pageable batches
+            # (H2D ~8 ms per batch) with two batches prefetched per worker
+            decoded = raw == "decoded"
             dl = DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds, replacement=True, num_samples=n_img), num_workers=workers,
-                            pin_memory=True, drop_last=True, prefetch_factor=4, persistent_workers=False,
-                            collate_fn=ragged_collate if raw == "decoded" else None)
+                            pin_memory=not decoded, drop_last=True, prefetch_factor=2 if decoded else 4, persistent_workers=False,
+                            collate_fn=ragged_collate if decoded else None)
             aug = DeviceAugment(224, train=True, dtype=torch.bfloat16) if raw else None
-            rz = DeviceResize(224, device) if raw == "decoded" else None
+            rz = DeviceResize(224, device) if decoded else None
             it = iter(dl)
-            for _ in range(3):                                # worker start-up + first batches
-                next(it)
+            for _ in range(3):                                # worker start-up + first batches (through the device path once: first-use costs)
+                b = next(it)
+                if rz is not None:
+                    aug(rz(b[0], b[1]))
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             n = 0
