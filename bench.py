@@ -373,7 +373,7 @@ def fds_kernel_rooflines(device):
     fmap = torch.rand(b, c, h, w, device=device, generator=g)
     outm = torch.empty_like(fmap)
     ms = event_time_ms(lambda i: ops.calibrate_nchw(fmap, bins, t1, sc, t2, out=outm), 10)
-    out.append(row("dir_fds_calibrate_fwd_nchw (NYUD2 map in its own NCHW layout, tables in LDS)", "hbm", f"[{b},{c},{h},{w}] f32, 93 buckets", ms,
+    out.append(row("dir_fds_calibrate_fwd_nchw (NYUD2 map in its own NCHW layout: 16 KB plane chunks in address order, the channel's table column in LDS)", "hbm", f"[{b},{c},{h},{w}] f32, 93 buckets", ms,
                    2 * fmap.numel() * 4 + 3 * 93 * c * 4 + rows.shape[0] * 4))
     del fmap, outm
     ms = event_time_ms(lambda i: ops.scatter_stats(rows, bins, 93), 5)

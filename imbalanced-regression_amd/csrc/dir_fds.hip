@@ -839,25 +839,29 @@ extern "C" int dir_fds_calibrate_fwd_lds(void* x_inout, int dtype, const int32_t
 // lanes of a wavefront — same channel, neighbouring pixels, nearby bins — hit different banks (or broadcast).
 // BWD: dx = dy * scale (scale < 0: untouched column) with only the multiplier table staged.
 // ---------------------------------------------------------------------------------------------
+// Channel split (round 4): one workgroup covers 4096 pixels, so the NYUD2 map [32, 128, 114, 152] is only 136 pixel blocks — half the CUs
+// idle, and the 147 KB of tables allow one workgroup per CU. blockIdx.y picks a channel GROUP of CG = C / gridDim.y channels: the
+// workgroup stages only its group's table slices (73 KB at two groups: two workgroups per CU) and walks only those channel planes.
 template <bool BWD>
 __global__ void __launch_bounds__(FDS_LDS_TPB)
 fds_calibrate_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ bins,
-                          long long npix, int C, int HW, int nb, int nbp,
+                          long long npix, int C, int HW, int nb, int nbp, int CG,
                           const float* __restrict__ m1, const float* __restrict__ scale, const float* __restrict__ m2) {
-    extern __shared__ __attribute__((aligned(16))) float fds_tab[];      // [T][C][nbp], T = 3 (forward: m1, scale, m2) or 1 (scale)
+    extern __shared__ __attribute__((aligned(16))) float fds_tab[];      // [T][CG][nbp], T = 3 (forward: m1, scale, m2) or 1 (scale)
     const int t = threadIdx.x;
+    const int c0 = blockIdx.y * CG;
     {
         const float* src[3] = {BWD ? scale : m1, scale, m2};
         const int T = BWD ? 1 : 3;
-        for (int i = t; i < T * nb * C; i += FDS_LDS_TPB) {              // coalesced over the [nb][C] source
-            const int which = i / (nb * C), rem = i - which * nb * C, b = rem / C, c = rem - b * C;
-            fds_tab[((size_t)which * C + c) * nbp + b] = src[which][rem];
+        for (int i = t; i < T * nb * CG; i += FDS_LDS_TPB) {             // coalesced over the [nb][c0 .. c0 + CG) slices of the source
+            const int which = i / (nb * CG), rem = i - which * nb * CG, b = rem / CG, c = rem - b * CG;
+            fds_tab[((size_t)which * CG + c) * nbp + b] = src[which][(size_t)b * C + c0 + c];
         }
     }
     __syncthreads();
     const float* t1 = fds_tab;
-    const float* ts = BWD ? fds_tab : fds_tab + (size_t)C * nbp;
-    const float* t2 = fds_tab + (size_t)2 * C * nbp;
+    const float* ts = BWD ? fds_tab : fds_tab + (size_t)CG * nbp;
+    const float* t2 = fds_tab + (size_t)2 * CG * nbp;
     const long long nquad = npix >> 2;
     for (long long q = (long long)blockIdx.x * FDS_LDS_TPB + t; q < nquad; q += (long long)gridDim.x * FDS_LDS_TPB) {
         const long long p = q << 2;
@@ -865,9 +869,9 @@ fds_calibrate_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, co
         const int hw = (int)(p - n * HW);
         const int4 b4 = *reinterpret_cast<const int4*>(bins + p);
         const int bn[4] = {b4.x, b4.y, b4.z, b4.w};
-        const size_t base = (size_t)n * C * HW + hw;
+        const size_t base = ((size_t)n * C + c0) * HW + hw;
 #pragma unroll 4
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CG; ++c) {
             const float4 v = fds_ldnt(x + base + (size_t)c * HW);
             float in[4] = {v.x, v.y, v.z, v.w}, out[4];
 #pragma unroll
@@ -882,6 +886,56 @@ fds_calibrate_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, co
     }
 }
 
+// Plane-chunk form (round 4; nb <= 128): short-lived 256-thread workgroups in ADDRESS order, each moving one contiguous 16 KB chunk of
+// ONE channel plane (four 4 KB pieces in flight per workgroup) — the access pattern a bare stream prefers on this part (6.3 TB/s
+// against 4.2-5.1 for grid-stride sweeps, profiles/r03_stream_patterns.txt). A plane needs only its channel's COLUMN of the tables:
+// 3 x nb floats in LDS (1.1 KB, fetched from the L2-resident [nb][C] tables), the bins of the chunk's pixels come from the L2 too
+// (re-read once per channel: 2.2 MB x 128 at NYUD2 shapes). Same calib1 arithmetic: bit-identical to the kernel above.
+template <bool BWD>
+__global__ void __launch_bounds__(DIR_TPB)
+fds_calibrate_nchw_plane_kernel(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ bins,
+                                int C, int HW, int nb, int chunks,
+                                const float* __restrict__ m1, const float* __restrict__ scale, const float* __restrict__ m2) {
+    __shared__ float tab[3][128];
+    const int t = threadIdx.x;
+    const int chunk = blockIdx.x % chunks;
+    const long long plane = blockIdx.x / chunks;                          // n * C + c
+    const int c = (int)(plane % C);
+    const long long n = plane / C;
+    if (t < nb) {
+        tab[1][t] = scale[(size_t)t * C + c];
+        if (!BWD) { tab[0][t] = m1[(size_t)t * C + c]; tab[2][t] = m2[(size_t)t * C + c]; }
+    }
+    __syncthreads();
+    const float* xp = x + (size_t)plane * HW;
+    float* yp = y + (size_t)plane * HW;
+    const int32_t* bp = bins + (size_t)n * HW;
+    const int p0 = chunk * (4 * DIR_TPB * 4) + t * 4;                     // 4096 pixels per chunk: four pieces of 1024
+    float4 v[4];
+    int4 b4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * DIR_TPB * 4;
+        if (p < HW) { v[u] = fds_ldnt(xp + p); b4[u] = *reinterpret_cast<const int4*>(bp + p); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * DIR_TPB * 4;
+        if (p >= HW) continue;
+        const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const int bn[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (bn[k] < 0) { out[k] = in[k]; continue; }
+            const float sc = tab[1][bn[k]];
+            if (BWD) out[k] = sc < 0.0f ? in[k] : in[k] * sc;
+            else out[k] = calib1(in[k], tab[0][bn[k]], sc, tab[2][bn[k]]);
+        }
+        fds_stnt(yp + p, make_float4(out[0], out[1], out[2], out[3]));
+    }
+}
+
 // x, y: [N, C, HW] float32 (NCHW maps, HW = H * W a multiple of 4, 16-byte aligned); bins: [N * HW] int32 (< 0: pixel copied
 // unchanged). y may alias x. Returns DIR_EUNSUPPORTED when the tables do not fit a CU's LDS or the layout does not allow
 // 16-byte accesses (the caller then takes the row form).
@@ -891,17 +945,33 @@ static int fds_nchw_launch(bool bwd, const float* x, float* y, const int32_t* bi
     if (N == 0) return DIR_OK;
     DIR_RETURN_IF(!x || !y || !bins || !scale || (!bwd && (!m1 || !m2)), DIR_EINVAL);
     DIR_RETURN_IF((HW & 3) || !dir_aligned16(x) || !dir_aligned16(y) || !dir_aligned16(bins), DIR_EUNSUPPORTED);
+    if (nb <= 128 && N * (long long)C * dir_cdiv(HW, 4096) < (1ll << 31)) {
+        const int chunks = dir_cdiv(HW, 4096);
+        const unsigned grid = (unsigned)(N * C * chunks);
+        if (bwd) hipLaunchKernelGGL(fds_calibrate_nchw_plane_kernel<true>, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), x, y, bins, C, HW, nb, chunks, m1, scale, m2);
+        else hipLaunchKernelGGL(fds_calibrate_nchw_plane_kernel<false>, dim3(grid), dim3(DIR_TPB), 0, dir_s(stream), x, y, bins, C, HW, nb, chunks, m1, scale, m2);
+        DIR_LAUNCH_CHECK();
+        return DIR_OK;
+    }
     const int nbp = (nb + 3) & ~3;
-    const size_t lds = (size_t)(bwd ? 1 : 3) * C * nbp * 4;
-    DIR_RETURN_IF(lds > 160 * 1024, DIR_EUNSUPPORTED);
     const long long npix = N * (long long)HW;
-    long long want = (npix / 4 + FDS_LDS_TPB - 1) / FDS_LDS_TPB;
-    int grid = (int)(want < 256 ? (want < 1 ? 1 : want) : 256);
-    if (lds <= 64 * 1024 && want > 256) grid = (int)(want < 512 ? want : 512);
+    long long want = (npix / 4 + FDS_LDS_TPB - 1) / FDS_LDS_TPB;         // pixel blocks of 4096
+    // channel groups: as many as it takes to put >= 2 workgroups on every CU (while a group keeps >= 16 channels and C divides), and
+    // at least enough for the group's table slices to fit a CU's LDS
+    int groups = 1;
+    while ((size_t)(bwd ? 1 : 3) * (C / groups) * nbp * 4 > 160 * 1024 && (C / groups) % 2 == 0 && C / groups > 16) groups *= 2;
+    while (want * groups < 512 && (C / groups) % 2 == 0 && C / groups > 16) groups *= 2;
+    const int CG = C / groups;
+    const size_t lds = (size_t)(bwd ? 1 : 3) * CG * nbp * 4;
+    DIR_RETURN_IF(lds > 160 * 1024, DIR_EUNSUPPORTED);
+    // one workgroup per pixel block while that stays under ~2048 workgroups (the dispatcher balances them over the 256-512 resident
+    // slots: two 1024-thread workgroups per CU when the slices take <= 80 KB); beyond that a grid-stride sweep amortises the table staging
+    long long cap = (2048 + groups - 1) / groups;
+    int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
     DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_calibrate_nchw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (bwd) hipLaunchKernelGGL(fds_calibrate_nchw_kernel<true>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
-    else hipLaunchKernelGGL(fds_calibrate_nchw_kernel<false>, dim3(grid), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, m1, scale, m2);
+    if (bwd) hipLaunchKernelGGL(fds_calibrate_nchw_kernel<true>, dim3(grid, groups), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, CG, m1, scale, m2);
+    else hipLaunchKernelGGL(fds_calibrate_nchw_kernel<false>, dim3(grid, groups), dim3(FDS_LDS_TPB), lds, dir_s(stream), x, y, bins, npix, C, HW, nb, nbp, CG, m1, scale, m2);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

@@ -93,7 +93,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
     the pooled gradient + one fused pool-backward / BatchNorm-apply pass (``dir_bn_relu_maxpool_*``)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, partial=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, partial=None, want_xmax=True):
         x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
         n, c, h, w = x.shape
         m = n * h * w
@@ -114,7 +114,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         y = torch.empty((n, c, ho, wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
         # x at the argmax, for the backward's sum g * x (pooled size: 1/4 of x); None = the older pair (gather reduction, per-pixel apply)
-        xmax = torch.empty_like(y) if _STEM_TAIL_XMAX else None
+        xmax = torch.empty_like(y) if (_STEM_TAIL_XMAX and want_xmax) else None   # (no backward, e.g. the no-grad epoch-tail forward: not written at all)
         L.check(L.lib().dir_bn_relu_maxpool_fwd_xmax(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), L.ptr(xmax), n, h, w, c, stream),
                 "dir_bn_relu_maxpool_fwd_xmax")
         ctx.save_for_backward(x, gamma, mean, rstd, idx, xmax)
@@ -136,7 +136,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         L.check(L.lib().dir_bn_relu_maxpool_bwd_xmax(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(xmax), L.ptr(dx), n, h, w, c, L.ptr(gamma), L.ptr(mean),
                                                      L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
                 "dir_bn_relu_maxpool_bwd_xmax")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 _STEM_TAIL_XMAX = True
@@ -162,5 +162,5 @@ def bn_relu_maxpool(x, bn, pool, partial=None):
     if not ok:
         return maxpool3x3s2(bn_act(x, bn, relu=True, partial=partial), pool)
     _count_batch(bn)
-    return _BnReluMaxPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, partial)
+    return _BnReluMaxPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, partial, torch.is_grad_enabled())
 

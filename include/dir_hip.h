@@ -144,8 +144,10 @@ int dir_fds_calibrate_fwd_lds(void* x_inout, int dtype, const int32_t* bins, lon
                               const float* m1, const float* scale, const float* m2, dir_stream_t stream);
 /* K5 / K6 of the NYUD2-DIR dense variant on the network's own NCHW map (nyud2-dir/models/fds.py:128-149 permutes the map to
  * [B*H*W, C] and back around the calibration: two copies of 284 MB).  x, y: [N, C, HW] float32, HW % 4 == 0, 16-byte aligned;
- * bins [N * HW] int32 per pixel (< 0: copied unchanged); all three [nb, C] tables live transposed in LDS ([C][nb]); y may alias x.
- * DIR_EUNSUPPORTED when the tables do not fit (3 x C x nb x 4 B > 160 KB) or the layout does not allow 16-byte accesses. */
+ * bins [N * HW] int32 per pixel (< 0: copied unchanged); y may alias x.  nb <= 128: short-lived workgroups in address order, each one
+ * contiguous 16 KB chunk of ONE channel plane with that channel's column of the tables (3 x nb floats) in LDS; larger nb: persistent
+ * workgroups per (4096-pixel block, channel group) with the group's table slices transposed in LDS ([C / groups][nb]).
+ * DIR_EUNSUPPORTED when neither fits or the layout does not allow 16-byte accesses. */
 int dir_fds_calibrate_fwd_nchw(const void* x, void* y, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
                                const float* m1, const float* scale, const float* m2, dir_stream_t stream);
 int dir_fds_calibrate_bwd_nchw(const void* dy, void* dx, int dtype, const int32_t* bins, long long N, int C, int HW, int nb,
