@@ -122,6 +122,32 @@ def test_conv_wgrad_matches_fp32_reference(case):
     assert torch.equal(dw, conv2d_wgrad(dy, x, k, stride, pad))
 
 
+@pytest.mark.parametrize("n,cin,cout,hw", [(7, 256, 1024, 14), (3, 1024, 256, 14), (5, 512, 128, 28), (33, 128, 128, 7), (1, 128, 256, 5), (64, 2048, 512, 7)])
+def test_conv_wgrad_1x1_forms_agree(n, cin, cout, hw):
+    """The three forms of the 1x1 / stride-1 weight gradient, chosen per launch (DIR_WGRAD_*): the transposing kernel, and the register-lean
+    LDS-DMA + ds_read_b64_tr_b16 kernel with one / two LDS stages (the product's choice for 128-multiples of channels) — each against a
+    float64 reference (ragged last K-step, one to hundreds of split-K ranges), each deterministic; the forced DMA forms refuse other geometries."""
+    from dirhip import _lib as L
+    from dirhip.conv import conv2d_wgrad
+    g = torch.Generator(device="cuda").manual_seed(n + cin + cout + hw)
+    x = torch.randn(n, cin, hw, hw, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, cout, hw, hw, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref = torch.einsum("nohw,nihw->oi", dy.double(), x.double()).cpu().numpy()
+    outs = {}
+    for form in (L.WGRAD_AUTO, L.WGRAD_TRANSPOSE, L.WGRAD_DMA1, L.WGRAD_DMA2):
+        dw = conv2d_wgrad(dy, x, 1, 1, 0, form=form)
+        assert_close(dw.view(cout, cin).cpu().numpy(), ref, rtol=2e-5, atol_scale=2e-6, msg=f"form {form}")
+        assert torch.equal(dw, conv2d_wgrad(dy, x, 1, 1, 0, form=form))
+        outs[form] = dw
+    assert torch.equal(outs[L.WGRAD_AUTO], outs[L.WGRAD_DMA2])                       # what the product runs for these shapes
+    # not a 1x1 / stride-1 / 128-multiple geometry: the forced DMA forms are refused, AUTO takes the transposing kernel
+    lib = L.lib()
+    assert lib.dir_conv_wgrad_workspace(n, hw, hw, 64, cout, 1, 1, 1, 0, L.WGRAD_DMA2) == 0
+    assert lib.dir_conv_wgrad_workspace(n, hw, hw, cin, cout, 3, 3, 1, 1, L.WGRAD_DMA1) == 0
+    assert lib.dir_conv_wgrad_workspace(n, hw, hw, 64, cout, 1, 1, 1, 0, L.WGRAD_AUTO) > 0
+    assert lib.dir_conv_wgrad_workspace(n, hw, hw, cin, cout, 1, 1, 1, 0, 7) == 0
+
+
 def test_bottleneck_fused_shortcut_gradient_matches_unfused():
     """Identity-shortcut bottleneck: the gradient accumulation at the block input (dgrad(conv1) + d shortcut) fused into
     conv1's data-gradient kernel must give the same input/parameter gradients as autograd's eager add."""
