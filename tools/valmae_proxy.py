@@ -10,7 +10,7 @@ AgeDB-DIR train histogram (tests/golden/lds_weights.npz: in_labels_agedb), valid
 reference's curated val sets are). ResNet-50 + LDS (sqrt_inv, gaussian 5/2) + FDS (agedb defaults), l1 loss, Adam 1e-3, the drop-in
 train_step / epoch_tail / validate / shot_metrics. For every seed the two modes share the initial weights and the batch order.
 
-    python tools/valmae_proxy.py [seeds=5] [epochs=4] [n_train=8192] [batch=64]   ->  gpurun_out/valmae_proxy.json (commit as profiles/rNN_valmae_proxy.json)"""
+    python tools/valmae_proxy.py [seeds=5] [epochs=4] [n_train=8192] [batch=64] [lr decay at epoch, 0 = none]   ->  gpurun_out/valmae_proxy.json (commit as profiles/rNN_valmae_proxy.json)"""
 import json
 import os
 import sys
@@ -51,7 +51,7 @@ def make_task(device, n_train, n_val, seed=1234):
     return y_train, y_val, images(y_train, seed + 1), images(y_val, seed + 2)
 
 
-def run_one(mode, seed, task, epochs, batch, device):
+def run_one(mode, seed, task, epochs, batch, device, decay_at=0):
     from dirhip import lds
     from dirhip.optim import Adam
     from dirhip.parallel import DataParallelEngine
@@ -72,6 +72,9 @@ def run_one(mode, seed, task, epochs, batch, device):
     store = EpochFeatures(n, 2048, device)
     order_gen = torch.Generator().manual_seed(10_000 + seed)
     for epoch in range(epochs):
+        if decay_at and epoch == decay_at:                            # the reference's step schedule (train.py: adjust_learning_rate, x0.1), once
+            for gp in opt.param_groups:
+                gp["lr"] = gp["lr"] * 0.1
         eng.train()
         perm = torch.randperm(n, generator=order_gen).to(device)
         idx = [perm[s:s + batch] for s in range(0, n - batch + 1, batch)]
@@ -97,6 +100,7 @@ def main():
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     n_train = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+    decay_at = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     task = make_task(device, n_train, 2048)
@@ -105,13 +109,13 @@ def main():
     for seed in range(seeds):
         for mode in ("bf16", "float32"):
             t1 = time.time()
-            r = run_one(mode, seed, task, epochs, batch, device)
+            r = run_one(mode, seed, task, epochs, batch, device, decay_at)
             r["seconds"] = time.time() - t1
             res[mode].append(r)
             print(f"seed {seed} {mode}: {r}", flush=True)
     out = {"task": "synthetic teacher task (tools/valmae_proxy.py): 224x224 images = fixed random low-resolution patterns with age-dependent coefficients + N(0,1) noise; "
                    f"{n_train} train labels from the AgeDB-DIR train histogram (long-tailed), 2048 balanced validation labels; ResNet-50 + LDS + FDS, l1, Adam 1e-3, "
-                   f"batch {batch}, {epochs} epochs, the drop-in train_step / epoch_tail / validate / shot_metrics",
+                   f"batch {batch}, {epochs} epochs" + (f" (lr x0.1 from epoch {decay_at})" if decay_at else "") + ", the drop-in train_step / epoch_tail / validate / shot_metrics",
            "seeds": seeds, "per_seed": res, "metric": "validation L1 (= val MAE, years): all / many-shot / median-shot / few-shot (train.py:286-391)"}
     summ = {}
     for mode, rows in res.items():
