@@ -80,14 +80,14 @@ def conv_flops_per_image():
     return tot
 
 
-def build(args, device, rank, amp_dtype=torch.bfloat16):
+def build(args, device, rank, amp_dtype=torch.bfloat16, force_collectives=False):
     from dirhip import lds
     from dirhip.parallel import DataParallelEngine
     from dirhip.resnet import resnet50
     torch.manual_seed(0)
     model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1,
                      kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
-    engine = DataParallelEngine(model, amp_dtype=amp_dtype, channels_last=True)
+    engine = DataParallelEngine(model, amp_dtype=amp_dtype, channels_last=True, force_collectives=force_collectives)
     engine.train()
     from dirhip.optim import Adam
     optimizer = Adam(engine.parameters(), lr=1e-3)          # torch.optim.Adam's arithmetic and state, one HIP launch (+ the bf16 weight operands)
@@ -744,6 +744,8 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--no-float32-mode", action="store_true", help="skip the float32 (parity-exact) mode leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic stays null)")
+    ap.add_argument("--force-collectives", action="store_true", help="N = 1 only: run the loop through the engine's N > 1 branch in a ONE-rank nccl (RCCL) "
+                    "group — gradient hooks, bucket all-reduces, FDS statistic merge — to price that machinery on one GPU (`comm` object in the line)")
     ap.add_argument("--full-probes", action="store_true", help="N > 1 only: rank 0 also runs the per-layer / FDS-kernel / input-pipeline probes "
                     "that the N = 1 line carries (by default an N > 1 line carries roofline, step breakdown, peaks, comm, cpu_baseline)")
     args = ap.parse_args()
@@ -759,9 +761,17 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU (the hot path has no CPU fallback)")
     device = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(device)
+    forced = bool(args.force_collectives and world == 1)
+    if forced:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
-    model, engine, optimizer, batches = build(args, device, rank)
+    model, engine, optimizer, batches = build(args, device, rank, force_collectives=forced)
     store = EpochFeatures(args.epoch_len * args.batch, 2048, device)
     loss_fn = resolve_loss("l1")
     log("model + data built")
@@ -806,13 +816,17 @@ def main():
     }
     result["roofline"] = dict(result["roofline_loop"], traffic=None)      # replaced below by the dominant kernel's when measured
     # ---- measurements that still need every rank (collectives inside the steps): communication report, in-situ kernel times
-    if world > 1:
+    if world > 1 or forced:
         result["comm"] = comm_probe(engine, optimizer, batches, loss_fn, epoch, device, world)
+        if forced:
+            result["comm"]["note_forced"] = ("ONE-rank nccl group on one GPU (--force-collectives): every collective is the identity; what this line prices is the "
+                                             "machinery — 161 post-accumulate hooks, 3 bucket all-reduce launches per step, the FDS statistic merge per epoch tail — "
+                                             "against the same loop without it (the default N = 1 line)")
     fam = None
     if not args.no_kernel_rooflines:
         fam = in_situ_breakdown(engine, optimizer, batches, loss_fn, epoch)
         log("in-situ kernel breakdown done")
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:

@@ -41,3 +41,33 @@ def test_bench_self_spawns_its_ranks_when_started_without_a_launcher():
     assert p.stderr.count("bench.py needs an AMD GPU") >= 1, p.stderr[-2000:]          # the ranks came up and met the GPU gate
     assert "but the launcher started" not in p.stderr and "AssertionError" not in p.stderr
     assert p.returncode != 0                                                          # no GPU: the failure is loud, not a fake line
+
+
+def test_ragged_collate_packs_decoded_images_for_the_gpu_resize():
+    """raw="decoded" datasets hand out images at their file size; `ragged_collate` packs a batch as one flat uint8 buffer + an (H, W) table
+    (+ labels, weights and any further per-sample items such as the shard-padding flag) — the host half of DeviceResize."""
+    from dirhip.datasets import ragged_collate
+    rng = np.random.default_rng(0)
+    shapes = [(5, 7), (3, 3), (8, 2)]
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in shapes]
+    samples = [(im, np.asarray([20.0 + i], np.float32), np.asarray([1.5], np.float32), i % 2 == 0) for i, im in enumerate(imgs)]
+    flat, sizes, labels, weights, valid = ragged_collate(samples)
+    assert flat.dtype == torch.uint8 and flat.numel() == sum(h * w * 3 for h, w in shapes) and sizes.tolist() == [list(s) for s in shapes]
+    off = 0
+    for im in imgs:
+        assert torch.equal(flat[off:off + im.numel()].view(im.shape), im)
+        off += im.numel()
+    assert labels.shape == (3, 1) and weights.shape == (3, 1) and valid.tolist() == [True, False, True]
+    assert ragged_collate([s[:3] for s in samples])[3].shape == (3, 1) and len(ragged_collate([s[:3] for s in samples])) == 4
+
+
+def test_device_resize_refuses_cpu_target():
+    from dirhip import _lib as L
+    from dirhip.datasets import DeviceResize
+    with pytest.raises(L.DirHipError):
+        DeviceResize(224, device="cpu")(torch.zeros(12, dtype=torch.uint8), torch.tensor([[2, 2]]))
+    lib = L.lib()
+    assert lib.dir_resize_ksize(320, 224) == 5 and lib.dir_resize_ksize(100, 224) == 3 and lib.dir_resize_ksize(2048, 224) == 21 and lib.dir_resize_ksize(0, 224) == 0
+    assert lib.dir_resize_u8_workspace(256, 224, 5, 1000) > 256 * 2 * 224 * 7 * 4 and lib.dir_resize_u8_workspace(0, 224, 5, 0) == 0
+    assert lib.dir_resize_u8(None, None, None, 1, 224, 10, 3, None, 0, None) == -1
+    assert lib.dir_sgd_step(None, 1, 0.1, 0.9, 0.0, 0.0, 0, 0, None) == -1
