@@ -752,6 +752,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_spawn(args))
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 on their own (RCCL prints a five-line version
+    # banner there when it initialises) are pointed at stderr for the life of the process; the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     args.epoch_len = max(1, min(args.epoch_len, args.steps))      # at least one epoch tail inside the timed region
     from dirhip.parallel import init_distributed
     rank, world, local_rank = init_distributed(backend=args.backend)
@@ -966,7 +971,8 @@ def main():
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         log("cpu baseline done")
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":
