@@ -12,17 +12,17 @@
 #define DIR_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // One-time per-DEVICE setup of a launch site (hipFuncSetAttribute for kernels with > 64 KB of dynamic LDS): a process may drive
-// several GPUs (the attribute is per device), so the "done" flag is a bit per device ordinal, not a process-wide bool. The setup
-// calls are idempotent: two threads racing through the first use both make them.
-static inline bool dir_first_use_on_device(std::atomic<uint64_t>& done) {
+// several GPUs (the attribute is per device), so the "done" flag is a bit per device ordinal, not a process-wide bool. The setup runs
+// BEFORE the bit is published (release), so a second thread that sees the bit (acquire) also sees a configured function; two threads
+// racing through the first use both make the (idempotent) calls.
+static inline uint64_t dir_device_setup_pending(std::atomic<uint64_t>& done) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_relaxed) & bit) return false;
-    done.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+    return (done.load(std::memory_order_acquire) & bit) ? 0 : bit;
 }
-#define DIR_ONCE_PER_DEVICE(...) do { static std::atomic<uint64_t> done_{0}; if (dir_first_use_on_device(done_)) { __VA_ARGS__; } } while (0)
+#define DIR_ONCE_PER_DEVICE(...) do { static std::atomic<uint64_t> done_{0}; const uint64_t bit_ = dir_device_setup_pending(done_); \
+                                      if (bit_) { __VA_ARGS__; done_.fetch_or(bit_, std::memory_order_release); } } while (0)
 
 static inline hipStream_t dir_s(dir_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool dir_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -2,7 +2,7 @@
 kernel with Cin/Cout swapped) at batch B through dir_conv_fwd_variant, K-loop variants side by side (1 = register-staged,
 2 = LDS-DMA), interleaved in one process, inputs rotated over enough distinct buffers that the working set exceeds the
 256 MB Infinity Cache. Prints per-layer microseconds, TFLOP/s and the per-layer roofline max(FLOP / 2.5 PF, bytes / 8 TB/s).
-    python tools/probe_conv_variants.py [B] [variants, e.g. 1,2]"""
+    python tools/probe_conv_variants.py [B] [variants, e.g. 1,2] [library to load instead of the product's, or -] [rows = only the row-resident kernel's launches]"""
 import os
 import sys
 
@@ -28,6 +28,9 @@ def run(x, w, y, st, n, h, cin, cout, k, stride, pad, variant):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
+    if len(sys.argv) > 3 and sys.argv[3] != "-":
+        L.LIB_PATH = os.path.abspath(sys.argv[3])
+    only_rows = len(sys.argv) > 4 and sys.argv[4] == "rows"        # only the launches the row-resident 1x1 kernel takes
     dev = torch.device("cuda")
     tot = {v: [0.0, 0.0] for v in variants}
     tot_roof = [0.0, 0.0]
@@ -37,6 +40,8 @@ def main():
         ho = (h + 2 * pad - k) // st + 1
         for kind, ci, co, hh, s_ in (("fwd", cin, cout, h, st),) + ((("dgrad", cout, cin, ho, 1),) if st == 1 else ()):
             hout = (hh + 2 * pad - k) // s_ + 1
+            if only_rows and not (k == 1 and ci <= 256 and co >= 256):
+                continue
             nbytes = (B * hh * hh * ci + B * hout * hout * co) * 2
             nbuf = max(2, min(8, int(600e6 // nbytes) + 1))
             xs = [torch.randn(B, ci, hh, hh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
