@@ -778,14 +778,12 @@ extern "C" size_t dir_conv_stats_rows(int N, int Ho, int Wo) {
 //   variant 1 / 2               128 x 128 (x 64) tiles, register-staged / LDS-DMA K loop
 //   variant 3                   patch-staged 3x3 (3x3 / stride 1 / pad 1 on square 56, 28, 14 maps only)
 //   variant 5                   256 x 256 CU tile (Cout % 256 == 0, M % 256 == 0)
-//   variant 6                   row-resident 1x1 (dir_conv_rows.hip: Cin in {64, 128, 256}, Cout % 128 == 0, M % 128 == 0, slim epilogue)
 // Heuristic: the 256 x 256 CU tile from CVB_MIN_KT K-steps and CVB_MIN_TILES tiles (it loses on short K loops — the lone workgroup's
 // prologue / epilogue are exposed — and on the 7^2 layers' 98 tiles); else the patch-staged kernel for its shapes (M tiles = chunks of
 // whole image rows); else 128-row tiles: LDS-DMA from CV_DMA_MIN_KT K-steps, single-stage LDS-DMA at four workgroups per CU for
 // 128-wide launches of <= 18 steps, register-staged otherwise.
 constexpr int CVB_MIN_KT = 16, CVB_MIN_TILES = 150;
-constexpr int CV_ROWS_AUTO = 20;   // bit KT set: AUTO gives the row-resident 1x1 kernel the launches with KT K-steps (Cin = 64 KT); 20 = Cin 128 and 256
-enum { CK_UNSUPPORTED = -1, CK_TILE = 0, CK_PATCH3 = 1, CK_BIG = 2, CK_ROWS = 3 };
+enum { CK_UNSUPPORTED = -1, CK_TILE = 0, CK_PATCH3 = 1, CK_BIG = 2 };
 struct ConvPlan { int kind; int cpw; size_t rows; };
 
 static int cp_chunks(int W) { return W == 56 ? 28 : W == 28 ? 7 : 2; }
@@ -805,10 +803,7 @@ static ConvPlan conv_plan(int N, int H, int W, int Cin, int Cout, int R, int S, 
     if (variant == DIR_CONV_PATCH3)
         return (!cls && cp_geometry(H, W, R, S, stride, pad)) ? ConvPlan{CK_PATCH3, W, (size_t)N * cp_chunks(W)} : ConvPlan{CK_UNSUPPORTED, 0, 0};
     if (variant == DIR_CONV_TILE_REG || variant == DIR_CONV_TILE_DMA) return ConvPlan{CK_TILE, 0, rows128};
-    if (variant == DIR_CONV_ROWS)
-        return (!cls && !two_addends && conv_rows_geometry(M, Cin, Cout, R, S, stride, pad)) ? ConvPlan{CK_ROWS, 0, rows128} : ConvPlan{CK_UNSUPPORTED, 0, 0};
     if (variant != DIR_CONV_AUTO) return ConvPlan{CK_UNSUPPORTED, 0, 0};
-    if (!cls && !two_addends && conv_rows_geometry(M, Cin, Cout, R, S, stride, pad) && ((CV_ROWS_AUTO >> (Cin / CV_BK)) & 1)) return ConvPlan{CK_ROWS, 0, rows128};
     if (!two_addends && conv_big_geometry(M, Cout, R * S) && R * S * (Cin / CV_BK) >= CVB_MIN_KT && (M / 256) * (Cout / 256) >= CVB_MIN_TILES)
         return ConvPlan{CK_BIG, 0, rows128};
     if (!cls && cp_geometry(H, W, R, S, stride, pad)) return ConvPlan{CK_PATCH3, W, (size_t)N * cp_chunks(W)};
@@ -945,7 +940,7 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
     DIR_RETURN_IF(M >= (1ll << 24) || (long long)N * H * W * Cin >= (1ll << 30) || M * Cout >= (1ll << 31) || R * S > 32, DIR_EUNSUPPORTED);   // 32-bit byte offsets into x
     // which kernel, and how it tiles M: the caller's statistics list must have exactly the rows that kernel writes
     const ConvPlan plan = conv_plan(N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, addend && addend_s2, cls, variant);
-    DIR_RETURN_IF(plan.kind == CK_UNSUPPORTED, (variant < 0 || variant > DIR_CONV_ROWS || variant == 4) ? DIR_EINVAL : DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(plan.kind == CK_UNSUPPORTED, (variant < 0 || variant > DIR_CONV_BIG || variant == 4) ? DIR_EINVAL : DIR_EUNSUPPORTED);
     DIR_RETURN_IF(stats && (size_t)stats_rows != plan.rows, DIR_EINVAL);
     ConvP p;
     p.x = static_cast<const uint16_t*>(x); p.w = static_cast<const uint16_t*>(w); p.y = static_cast<uint16_t*>(y);
@@ -984,13 +979,6 @@ static int conv_launch_ex(const void* x, const void* w, const void* addend, cons
 #undef CP_LAUNCH
         DIR_LAUNCH_CHECK();
         return DIR_OK;
-    }
-    if (plan.kind == CK_ROWS) {                                     // row-resident 1x1 (dir_conv_rows.hip)
-        // its slim epilogue has no tensor ReLU mask, compact stride-2 addend or mask recompute: such a launch stays on the 128-row tile kernels
-        // below (same statistics rows), or is refused when the kernel was forced
-        const bool slim = !p.mask && !p.addend2 && !p.bn_gamma;
-        if (slim) return conv_rows_launch(p, !p.addend && !p.mask_bits && !p.bnx, s);
-        DIR_RETURN_IF(variant == DIR_CONV_ROWS, DIR_EUNSUPPORTED);
     }
     if (plan.kind == CK_BIG) {
         // 256 x 256 CU tile on 16 wavefronts (half the LDS-DMA pieces per FLOP)

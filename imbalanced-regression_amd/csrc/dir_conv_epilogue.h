@@ -1,4 +1,4 @@
-// Epilogue of the MFMA implicit-GEMM convolution kernels (dir_conv.hip, dir_conv_rows.hip): bf16 staging tile -> 16-byte row stores with the
+// Epilogue of the MFMA implicit-GEMM convolution kernels (dir_conv.hip): bf16 staging tile -> 16-byte row stores with the
 // fused statistics / addend / ReLU-mask / BatchNorm-backward options. One definition, so that every kernel variant stores and sums in the same order
 // (outputs and partial-sum lists are bit-identical across variants: tools/check_conv_variants.py).
 #pragma once
@@ -41,10 +41,8 @@ __device__ __forceinline__ void cv_epilogue_stats(const ConvP& p, float (&ssum)[
 // cv_epilogue_staged: everything after the accumulators have been written to the staging tile Cs = smem [128 pixels][BN * 2 + 16 bytes] (by
 // cv_stage_acc, whatever the caller's wavefront tiling) and BEFORE the barrier that publishes it: t = 0 .. 255 (the 256 threads that own the tile).
 // Barriers executed: one (publishing the tile) + one more when p.stats is given (cv_epilogue_stats) — a caller whose workgroup has further
-// wavefronts (dir_conv_rows.hip's loader) must execute the same number.
-// SLIM: the launch is known to have no tensor ReLU mask, no compact stride-2 addend, no mask recompute and dense rows (p.mask, p.addend2,
-// p.bn_gamma, p.o2 all unset): those operand streams, the coefficient registers and the (n, ho, wo) decode are compiled out (dir_conv_rows.hip, whose register budget is 168 with 64 of them holding A).
-template <int BN, bool LEAN = false, int NBATCH = 2, bool SLIM = false>
+// wavefronts must execute the same number.
+template <int BN, bool LEAN = false, int NBATCH = 2>
 __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char* smem, int t, int m0, int n0, int mt) {
     constexpr int CS_STRIDE = BN * 2 + 16;                      // bytes per staging row
     unsigned char* Cs = smem;                                   // [128][CS_STRIDE] (<= 34 KB)
@@ -85,13 +83,12 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
         return;
     }
     const bool fwd_stats = p.stats && !p.bnx;
-    const bool decode = !SLIM && (p.o2 || p.addend2);           // rows need their (n, ho, wo)
-    const bool has_mask = !SLIM && p.mask;
+    const bool decode = p.o2 || p.addend2;                      // rows need their (n, ho, wo)
 
     // fused BatchNorm-backward partials: (sum g, sum g * bnx) of the gradient as stored, optionally under the recomputed ReLU mask
     float maf[8], mbf[8];
     auto mask_coefficients = [&]() {
-        if (!SLIM && p.bnx && p.bn_gamma) {
+        if (p.bnx && p.bn_gamma) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                       // same expression as dir_bn.hip's bn_mask_coef (= the forward's coefficients)
                 const int ch = n0 + sch * 8 + j;
@@ -116,15 +113,15 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
     // epilogue waits for a store to be acknowledged. With a conditional store or load in between it has to assume the shortest
     // path and emits `s_waitcnt vmcnt(0)` — in the general loop below that is one store round trip per row, eight in a row per
     // workgroup tile (found in the ISA; same-box A/B: -0.19 ms per train step for the dense launches, -0.07 ms more for the scattered ones).
-    if (SLIM || !(p.addend && p.addend2)) {
+    if (!(p.addend && p.addend2)) {
         // y-shaped operands span the whole result tensor (the scattered rows of a stride-2 class launch index it like y itself)
         const uint32_t ybytes = p.o2 ? (uint32_t)p.N * (uint32_t)p.OH * (uint32_t)p.OW * (uint32_t)p.Cout * 2u : (uint32_t)p.M * (uint32_t)p.Cout * 2u;
         const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(p.y, (short)0, (int)ybytes, 0x00020000);
         // ONE shortcut-gradient stream: the dense one (addend, same offsets as y) or the compact stride-2 one (addend2, own offsets)
-        const uint16_t* addp = (SLIM || p.addend) ? p.addend : p.addend2;
-        const uint32_t addbytes = (SLIM || p.addend) ? ybytes : (uint32_t)p.N * (uint32_t)(p.Ho >> 1) * (uint32_t)(p.Wo >> 1) * (uint32_t)p.Cout * 2u;
+        const uint16_t* addp = p.addend ? p.addend : p.addend2;
+        const uint32_t addbytes = p.addend ? ybytes : (uint32_t)p.N * (uint32_t)(p.Ho >> 1) * (uint32_t)(p.Wo >> 1) * (uint32_t)p.Cout * 2u;
         const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), (short)0, addp ? (int)addbytes : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.mask), (short)0, has_mask ? (int)ybytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.mask), (short)0, p.mask ? (int)ybytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_bnx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.bnx), (short)0, p.bnx ? (int)ybytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask_bits), (short)0, p.mask_bits ? (int)(ybytes >> 4) : 0, 0x00020000);
         const uint32_t gob = (uint32_t)go0 * 2u, gsb = (uint32_t)gstep * 2u;     // byte offsets of the thread's first row chunk / row step
@@ -153,7 +150,7 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
             }                                                                                                   \
             f_ob[set][ii] = ob; f_oa[set][ii] = oa;                                                             \
             f_add[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)oa, 0, 2);                       \
-            if constexpr (!SLIM) f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 2);   \
+            f_mask[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)ob, 0, 2);                     \
             f_bits[set][ii] = __builtin_amdgcn_raw_buffer_load_b8(r_bits, (int)(ob >> 4), 0, 0);                \
             f_bnx[set][ii] = __builtin_amdgcn_raw_buffer_load_b128(r_bnx, (int)ob, 0, 2);                       \
         }
@@ -179,7 +176,7 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
                 }
                 if (addp) {                                     // y = bf16(bf16(conv) + addend), like an eager add kernel
                     const uint32_t aw[4] = {f_add[set][ii].x, f_add[set][ii].y, f_add[set][ii].z, f_add[set][ii].w};
-                    const bool has = SLIM || p.addend || f_oa[set][ii] != (uint32_t)CV_OOB;   // (compact stream: even pixels only; the others keep their bits)
+                    const bool has = p.addend || f_oa[set][ii] != (uint32_t)CV_OOB;   // (compact stream: even pixels only; the others keep their bits)
 #pragma unroll
                     for (int q2 = 0; q2 < 4; ++q2) {
                         const uint32_t sum = cv_pack_bf16(__uint_as_float(cw[q2] << 16) + __uint_as_float(aw[q2] << 16),
@@ -187,7 +184,7 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
                         cw[q2] = has ? sum : cw[q2];
                     }
                 }
-                if (has_mask) {                                 // ReLU backward of the tensor this gradient belongs to
+                if (p.mask) {                                   // ReLU backward of the tensor this gradient belongs to
                     const uint32_t kw[4] = {f_mask[set][ii].x, f_mask[set][ii].y, f_mask[set][ii].z, f_mask[set][ii].w};
 #pragma unroll
                     for (int q2 = 0; q2 < 4; ++q2) {
@@ -210,7 +207,7 @@ __device__ __forceinline__ void cv_epilogue_staged(const ConvP& p, unsigned char
                     for (int q2 = 0; q2 < 4; ++q2) {
                         float g0 = __uint_as_float(cw[q2] << 16), g1 = __uint_as_float(cw[q2] & 0xffff0000u);
                         const float x0 = __uint_as_float(xw[q2] << 16), x1 = __uint_as_float(xw[q2] & 0xffff0000u);
-                        if (!SLIM && p.bn_gamma) {
+                        if (p.bn_gamma) {
                             if (!(x0 * maf[2 * q2] + mbf[2 * q2] > 0.0f)) g0 = 0.0f;
                             if (!(x1 * maf[2 * q2 + 1] + mbf[2 * q2 + 1] > 0.0f)) g1 = 0.0f;
                         }

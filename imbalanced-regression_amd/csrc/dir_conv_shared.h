@@ -26,9 +26,6 @@ struct ConvP {
     const uint16_t* bnx;
     const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_rstd;
 };
-// dir_conv_rows.hip: the row-resident 1x1 kernel (A fragments in registers, weights streamed by a loader wavefront)
-bool conv_rows_geometry(long long M, int Cin, int Cout, int R, int S, int stride, int pad);
-int conv_rows_launch(ConvP p, bool lean, hipStream_t s);
 struct ConvBn { const void* x; const float* gamma; const float* beta; const float* mean; const float* rstd; const void* mask_bits; };
 
 constexpr int CV_BM = 128, CV_BK = 64, CV_ROWB = CV_BK * 2;      // 128-byte LDS rows

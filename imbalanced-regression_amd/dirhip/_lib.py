@@ -126,7 +126,7 @@ SIGNATURES = {
 ABI_VERSION = 2
 DIR_F32, DIR_BF16 = 0, 1
 WGRAD_AUTO, WGRAD_TRANSPOSE, WGRAD_DMA1, WGRAD_DMA2 = 0, 1, 2, 3                             # DIR_WGRAD_*
-CONV_AUTO, CONV_TILE_REG, CONV_TILE_DMA, CONV_PATCH3, CONV_BIG, CONV_ROWS = 0, 1, 2, 3, 5, 6      # DIR_CONV_* of include/dir_hip.h
+CONV_AUTO, CONV_TILE_REG, CONV_TILE_DMA, CONV_PATCH3, CONV_BIG = 0, 1, 2, 3, 5      # DIR_CONV_* of include/dir_hip.h
 FLAG_HAS_LO, FLAG_HAS_HI, FLAG_NONINTEGER, FLAG_NAN = 1, 2, 4, 8
 FACTOR_ZERO, FACTOR_MOMENTUM, FACTOR_COUNT = 0, 1, 2
 LOSS_KINDS = {"mse": 0, "l1": 1, "focal_mse": 2, "focal_l1": 3, "huber": 4}

@@ -292,9 +292,7 @@ size_t dir_conv_stats_rows(int N, int Ho, int Wo);
  * taps read it there); 128-row tiles otherwise.  The other values force one kernel (tests, A/B measurements): the launch returns
  * DIR_EUNSUPPORTED when the geometry is not that kernel's. */
 enum { DIR_CONV_AUTO = 0, DIR_CONV_TILE_REG = 1 /* 128-row tiles, register-staged K loop */, DIR_CONV_TILE_DMA = 2 /* 128-row tiles,
-       LDS-DMA K loop */, DIR_CONV_PATCH3 = 3 /* patch-staged 3x3 */, DIR_CONV_BIG = 5 /* 256 x 256 CU tile: Cout % 256 == 0, M % 256 == 0 */,
-       DIR_CONV_ROWS = 6 /* row-resident 1x1 (round 5): 1x1 / pad 0 / stride 1 or 2, Cin in {64, 128, 256}, Cout % 128 == 0, M % 128 == 0:
-       the A fragments of a workgroup's 128 rows stay in registers over all its column tiles, a loader wavefront streams the weights */ };
+       LDS-DMA K loop */, DIR_CONV_PATCH3 = 3 /* patch-staged 3x3 */, DIR_CONV_BIG = 5 /* 256 x 256 CU tile: Cout % 256 == 0, M % 256 == 0 */ };
 /* Rows of the `stats` list of ONE launch of this geometry through `variant`: the kernels tile M differently (128 output pixels per
  * row for the tile and CU-tile kernels, one row per chunk of whole image rows for the patch-staged kernel), and which kernel AUTO
  * picks also depends on whether the launch carries BOTH fused addends (two_addends).  The host sizes `stats` with this function and

@@ -4,8 +4,7 @@ addend / compact stride-2 addend / ReLU bit mask / fused BatchNorm-backward sums
 of the stride-2 data gradient — outputs and partial-sum lists must be BIT-IDENTICAL (same K order per element, same epilogue, same
 summation order), plus an fp32 reference check of the forward.
     python tools/check_conv_variants.py big     # the 256 x 256 CU-tile kernel (5) against the 128-row LDS-DMA tile kernel (2)
-    python tools/check_conv_variants.py tiles   # LDS-DMA (2) against register-staged (1) 128-row tiles, ragged M included
-    python tools/check_conv_variants.py rows    # the row-resident 1x1 kernel (6) against the 128-row LDS-DMA tile kernel (2)"""
+    python tools/check_conv_variants.py tiles   # LDS-DMA (2) against register-staged (1) 128-row tiles, ragged M included"""
 import os
 import sys
 
@@ -139,16 +138,6 @@ def main():
             (64, 512, 256, 1, 14, False, True, True, True, False), (256, 2048, 512, 1, 7, False, False, False, True, True),
             (256, 512, 512, 3, 7, False, False, False, True, True), (64, 256, 256, 1, 14, True, False, False, False, False)]
         s2 = [(64, 256, 256, 14, False), (256, 512, 512, 7, True)]
-    elif what == "rows":
-        # every K-step count (Cin 64 / 128 / 256), stride 2, one / several column groups per row tile (few row tiles), long column walks; the
-        # data-gradient forms the kernel takes (dense addend, ReLU bits, BatchNorm-backward sums without mask recompute)
-        PAIR = (L.CONV_TILE_DMA, L.CONV_ROWS)
-        fwd = [(64, 256, 1024, 1, 1, 14), (16, 128, 512, 1, 1, 28), (4, 64, 256, 1, 1, 56), (16, 256, 512, 1, 2, 56), (64, 256, 512, 1, 1, 14),
-               (8, 128, 256, 1, 1, 16), (4, 256, 2048, 1, 1, 8), (256, 256, 1024, 1, 1, 14), (64, 128, 1024, 1, 2, 28), (4, 64, 128 * 5, 1, 1, 8)]
-        dg = [(64, 256, 1024, 1, 14, True, False, True, True, False), (16, 128, 512, 1, 28, True, False, True, True, False),
-              (64, 256, 1024, 1, 14, False, False, False, True, False), (4, 64, 256, 1, 56, True, False, False, False, False),
-              (64, 256, 512, 1, 14, False, False, True, False, False), (4, 256, 2048, 1, 8, True, False, True, True, False)]
-        s2 = []
     else:
         PAIR = (L.CONV_TILE_REG, L.CONV_TILE_DMA)
         fwd = [(3, 64, 256, 1, 1, 56), (3, 128, 512, 1, 1, 28), (5, 256, 1024, 1, 1, 14), (5, 1024, 256, 1, 1, 14), (3, 512, 2048, 1, 1, 7),
