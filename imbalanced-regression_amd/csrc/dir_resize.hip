@@ -55,13 +55,21 @@ __device__ __forceinline__ uint8_t rz_clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// The table lives in device memory, so the host entry point cannot validate it without a sync: each kernel checks the entry it works on
+// against what the launch was sized for (hmax rows of the grid, the tmp area behind the coefficient tables) and leaves an image it does not
+// fit untouched instead of writing out of bounds (dirhip.datasets.DeviceResize validates the same on the host before the launch).
+__device__ __forceinline__ bool rz_entry_fits(int H, int W, long long toff, int S, int hmax, long long tmp_bytes) {
+    return H > 0 && W > 0 && H <= hmax && toff >= 0 && toff + (long long)H * S * 3 <= tmp_bytes;
+}
+
 // horizontal: tmp[b][y][xx][c] = clip8((1 << 21) + sum_x src[b][y][xmin + x][c] * k[xx][x]); grid (ceil(Hmax * S / 256), B)
 __global__ void __launch_bounds__(DIR_TPB)
-resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ table, int S, int kmax, const int* __restrict__ bounds,
-                const int* __restrict__ kk, uint8_t* __restrict__ tmp) {
+resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ table, int S, int hmax, int kmax, long long tmp_bytes,
+                const int* __restrict__ bounds, const int* __restrict__ kk, uint8_t* __restrict__ tmp) {
     const int b = blockIdx.y;
     const long long soff = table[4 * b], toff = table[4 * b + 3];
     const int H = (int)table[4 * b + 1], W = (int)table[4 * b + 2];
+    if (!rz_entry_fits(H, W, toff, S, hmax, tmp_bytes)) return;     // a table entry the launch was not sized for: nothing is written for that image
     const long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x;
     if (i >= (long long)H * S) return;
     const int y = (int)(i / S), xx = (int)(i - (long long)y * S);
@@ -82,11 +90,12 @@ resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ t
 
 // vertical: out[b][yy][xx][c] = clip8((1 << 21) + sum_y tmp[b][ymin + y][xx][c] * k[yy][y]); grid (ceil(S * S / 256), B)
 __global__ void __launch_bounds__(DIR_TPB)
-resize_v_kernel(const uint8_t* __restrict__ tmp, const long long* __restrict__ table, int S, int kmax, const int* __restrict__ bounds,
-                const int* __restrict__ kk, uint8_t* __restrict__ out) {
+resize_v_kernel(const uint8_t* __restrict__ tmp, const long long* __restrict__ table, int S, int hmax, int kmax, long long tmp_bytes,
+                const int* __restrict__ bounds, const int* __restrict__ kk, uint8_t* __restrict__ out) {
     const int b = blockIdx.y;
     const long long toff = table[4 * b + 3];
     const int H = (int)table[4 * b + 1];
+    if (!rz_entry_fits(H, (int)table[4 * b + 2], toff, S, hmax, tmp_bytes)) return;
     const int i = blockIdx.x * DIR_TPB + threadIdx.x;
     if (i >= S * S) return;
     const int yy = i / S, xx = i - yy * S;
@@ -130,17 +139,18 @@ extern "C" int dir_resize_u8(const void* src, const long long* table, void* out,
     DIR_RETURN_IF(!src || !table || !out || !workspace || B <= 0 || S <= 0 || hmax <= 0 || kmax <= 0, DIR_EINVAL);
     DIR_RETURN_IF(B > 65535 || (long long)S * S >= (1ll << 31) || (long long)hmax * S >= (1ll << 31), DIR_EUNSUPPORTED);
     const size_t cb = rz_coef_bytes(B, S, kmax);
-    DIR_RETURN_IF(workspace_bytes < cb, DIR_EWORKSPACE);
+    DIR_RETURN_IF(workspace_bytes < cb + (size_t)S * 3, DIR_EWORKSPACE);       // (at least one intermediate row behind the coefficient tables)
+    const long long tmp_bytes = (long long)(workspace_bytes - cb);
     int* bounds = static_cast<int*>(workspace);
     int* kk = bounds + (size_t)B * 2 * S * 2;
     uint8_t* tmp = static_cast<uint8_t*>(workspace) + cb;            // (the host laid the intermediates out behind cb: table[b][3] are offsets into it)
     hipStream_t s = dir_s(stream);
     hipLaunchKernelGGL(resize_coeffs_kernel, dim3(B, 2), dim3(DIR_TPB), 0, s, table, S, kmax, bounds, kk);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(resize_h_kernel, dim3(dir_cdiv((long long)hmax * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, static_cast<const uint8_t*>(src), table, S, kmax,
-                       bounds, kk, tmp);
+    hipLaunchKernelGGL(resize_h_kernel, dim3(dir_cdiv((long long)hmax * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, static_cast<const uint8_t*>(src), table, S, hmax, kmax,
+                       tmp_bytes, bounds, kk, tmp);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(resize_v_kernel, dim3(dir_cdiv((long long)S * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, tmp, table, S, kmax, bounds, kk,
+    hipLaunchKernelGGL(resize_v_kernel, dim3(dir_cdiv((long long)S * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, tmp, table, S, hmax, kmax, tmp_bytes, bounds, kk,
                        static_cast<uint8_t*>(out));
     DIR_LAUNCH_CHECK();
     return DIR_OK;

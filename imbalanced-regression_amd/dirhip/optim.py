@@ -20,7 +20,10 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=False, fused=False, **kw)
         self._tables = {}                  # group index -> (key, device table)
 
-    def _ours(self, group, params):
+    def _ours(self, group, params, relay):
+        """Does the kernel take this group? Pure: state tensors that need the parameter's strides are only LISTED in ``relay``
+        (``(state dict, key, parameter)``); ``step`` re-lays them out once every group has passed (no state change before the
+        decision to fall back to torch's own step is final)."""
         if group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or group.get("capturable"):
             return False
         if isinstance(group["lr"], torch.Tensor):
@@ -41,7 +44,7 @@ class Adam(torch.optim.Adam):
                     if t.stride() != p.stride():
                         # e.g. a reference (NCHW-contiguous) optimizer checkpoint loaded next to channels_last parameters:
                         # load_state_dict keeps the loaded strides. Re-lay the moment out once, same values, the parameter's strides
-                        st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
+                        relay.append((st, k, p))
         return True
 
     def _drop_tables(self):
@@ -66,13 +69,16 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        relay = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            if not self._ours(group, params):
+            if not self._ours(group, params, relay):
                 super().step(None)                                          # torch's own step for every group (never a mix)
                 return loss
+        for st, k, p in relay:
+            st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
@@ -129,7 +135,8 @@ class SGD(torch.optim.SGD):
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov, foreach=False, fused=False, **kw)
         self._tables = {}
 
-    def _ours(self, group, params):
+    def _ours(self, group, params, relay):
+        """As ``Adam._ours``: pure, re-layouts only listed."""
         if group.get("maximize") or group.get("differentiable") or isinstance(group["lr"], torch.Tensor):
             return False
         dev = params[0].device
@@ -149,7 +156,7 @@ class SGD(torch.optim.SGD):
                 if not (buf.dtype == torch.float32 and buf.device == dev and buf.shape == p.shape):
                     return False
                 if buf.stride() != p.stride():                              # e.g. a reference checkpoint's NCHW buffers next to channels_last parameters
-                    self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(buf)
+                    relay.append((self.state[p], "momentum_buffer", p))
         return True
 
     def load_state_dict(self, state_dict):
@@ -171,24 +178,29 @@ class SGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        relay = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
-            if params and not self._ours(group, params):
+            if params and not self._ours(group, params, relay):
                 super().step(None)                                          # torch's own step for every group (never a mix)
                 return loss
+        for st, k, p in relay:
+            st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
             mom = float(group["momentum"])
             first = 0
+            new_bufs = None
             if mom != 0.0:
                 first = int(self.state[params[0]].get("momentum_buffer") is None)
                 if first:
-                    for p in params:
-                        self.state[p]["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)   # filled by the kernel (= clone(grad))
+                    # filled by the kernel (= clone(grad)); they enter the optimizer state only once the launch was accepted: a failed
+                    # launch must not leave uninitialised buffers behind that the next step would treat as momentum
+                    new_bufs = [torch.empty_like(p, memory_format=torch.preserve_format) for p in params]
             dev = params[0].device
-            bufs = [self.state[p]["momentum_buffer"] if mom != 0.0 else None for p in params]
+            bufs = new_bufs if new_bufs is not None else [self.state[p]["momentum_buffer"] if mom != 0.0 else None for p in params]
             key = tuple((p.data_ptr(), p.grad.data_ptr(), 0 if b is None else b.data_ptr()) for p, b in zip(params, bufs))
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
@@ -208,5 +220,8 @@ class SGD(torch.optim.SGD):
                 self._tables[gi] = cached
             L.check(L.lib().dir_sgd_step(L.ptr(cached[1]), len(params), float(group["lr"]), mom, float(group["dampening"]), float(group["weight_decay"]),
                                          int(bool(group["nesterov"])), first, L.stream_ptr(dev)), "dir_sgd_step")
+            if new_bufs is not None:
+                for p, b in zip(params, new_bufs):
+                    self.state[p]["momentum_buffer"] = b
             _conv.mark_prepared_after_step([pw for pw in cached[2] if pw is not None])
         return loss

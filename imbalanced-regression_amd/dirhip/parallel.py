@@ -151,6 +151,9 @@ class DataParallelEngine(nn.Module):
             return None
         if not self._decided:
             self._decided = True
+            # (held = "not None": a loop that keeps zero-valued gradients — zero_grad(set_to_none=False) — is classed as accumulating on every
+            #  step; the result is the same, it only pays one scaling kernel per bucket and step. Looking at the values would cost a device
+            #  sync per step; such loops should use set_to_none=True, torch's default.)
             self._accumulating = any(p.grad is not None for b in (self._buckets or []) for p in b.params)
         return None if self._accumulating else g * (1.0 / self.world)
 
@@ -241,6 +244,8 @@ class DataParallelEngine(nn.Module):
             self._pending_events = (ev_a, ev_b)
         self.stats["steps"] += 1
         self._callback_queued = False
+        self._decided = False               # every backward pass decides for itself (forward, forward, backward, backward: the second
+                                            # pass finds the first one's averaged gradients held and must take the accumulation form)
 
     def comm_report(self):
         """Observability of the N > 1 path (bench.py): ranks, bucket sizes, and — when ``measure_comm`` was on — the time the compute

@@ -317,14 +317,21 @@ def run(argv=None, dataset_default='imdb_wiki'):
         dev_resize = datasets.DeviceResize(args.img_size, device) if args.gpu_resize else None
         collate = datasets.ragged_collate if args.gpu_resize else None
 
+        # --gpu_resize hands over RAGGED file-size batches (~4x the bytes, a different size every time): pageable, like the configuration
+        # bench.py's input_pipeline leg measures — a pinned pool of varying block sizes takes tens of seconds to build and fragments the host
+        # caching allocator; fixed-size batches stay pinned
+        loader_kw = dict(num_workers=args.workers, pin_memory=not args.gpu_resize, collate_fn=collate)
+        if args.gpu_resize and args.workers > 0:
+            loader_kw["prefetch_factor"] = 2
+
         def train_batches(epoch):
             idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
             loader = DataLoader(_ShardSubset(train_set, idx.tolist(), valid.tolist()), batch_size=args.batch_size, shuffle=True,
-                                num_workers=args.workers, pin_memory=True, drop_last=False, collate_fn=collate)
+                                drop_last=False, **loader_kw)
             return lambda: _loader_batches(loader, device, aug_train, dev_resize)
 
         def eval_batches(ds):
-            loader = DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, pin_memory=True, collate_fn=collate)
+            loader = DataLoader(ds, batch_size=args.batch_size, shuffle=False, **loader_kw)
             return lambda: _loader_batches(loader, device, aug_eval, dev_resize)
         steps_per_epoch = (len(shard_indices(n_train, rank, world)) + args.batch_size - 1) // args.batch_size
         n_val = (len(val_set) + args.batch_size - 1) // args.batch_size
