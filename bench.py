@@ -380,6 +380,26 @@ def fds_kernel_rooflines(device):
     out.append(row("dir_fds_scatter_stats (narrow rows, NYUD2 dense map)", "hbm", f"N={rows.shape[0]} C={c} Nb=93 f32", ms,
                    rows.numel() * 4 + rows.shape[0] * 4))
     del rows
+    # --- STS-B-DIR (BASELINE configs[4]; sts-b-dir/fds.py:96-143, util.py:63-73): C = 12000 sentence features, 50 histogram buckets on [0, 5],
+    # clip [0.5, 2]: the batch call ([128, 12000], launch bound) and an HBM-resident size, and the epoch statistics at C = 12000
+    c, nb = 12000, 50
+    edges = torch.tensor(np.histogram(np.array([], np.float32), bins=nb, range=(0., 5.))[1].astype(np.float32), device=device)
+    t1, sc, t2 = (torch.rand(nb, c, device=device, generator=g) + 0.5 for _ in range(3))
+    for b in (128, 16384):
+        lab = torch.rand(b, device=device, generator=g) * 5.0
+        bins_b = ops.bin_edges(lab, edges, 0, nb)
+        u = int(torch.unique(bins_b).numel())
+        x = torch.randn(b, c, device=device, generator=g)
+        ms = event_time_ms(lambda i: ops.calibrate_fwd_(x, bins_b, t1, sc, t2), 50 if b == 128 else 10)
+        out.append(row("dir_fds_calibrate_fwd (STS-B: C = 12000, 50 buckets)", "hbm" if b > 2048 else "launch", f"B={b} C={c} U={u} T=3 f32", ms,
+                       2 * b * c * 4 + 3 * u * c * 4 + b * 4))
+        dy = torch.randn(b, c, device=device, generator=g)
+        ms = event_time_ms(lambda i: ops.calibrate_bwd(dy, bins_b, sc), 50 if b == 128 else 10)
+        out.append(row("dir_fds_calibrate_bwd (STS-B)", "hbm" if b > 2048 else "launch", f"B={b} C={c} U={u} f32", ms, 2 * b * c * 4 + u * c * 4 + b * 4))
+        if b > 2048:
+            ms = event_time_ms(lambda i: ops.scatter_stats(x, bins_b, nb), 10)
+            out.append(row("dir_fds_scatter_stats (STS-B: C = 12000)", "hbm", f"N={b} C={c} Nb={nb} f32", ms, b * c * 4 + b * 4))
+        del x, dy
     return out
 
 
@@ -478,6 +498,14 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
         out["decode_only_workers_gpu_resize_augment"] = {"images_per_sec": r, "h2d_plus_dir_resize_u8_plus_dir_augment_u8_ms_per_batch": ms,
                                                          "network_input": f"{shp} {dt_} channels_last", "keeps_up_with_consumer": bool(r >= consumer_img_s),
                                                          "what": "workers: PIL decode only (file-size uint8, ragged batch); GPU: dir_resize_u8 (Pillow bilinear, bit-exact) + dir_augment_u8"}
+        # ---- end to end: TRAIN from the files. The real DataLoader (decode-only workers, ragged batches) -> DeviceResize ->
+        # DeviceAugment -> train_step, and the epoch-tail forward from a second pass over the loader (as train.py:269-281 re-reads the training
+        # set), one tail batch per trained batch like the headline loop: images/s next to the synthetic `value`, plus the host time spent
+        # blocked in the loader (a stall only matters once it exceeds the slack the device-bound loop leaves the host).
+        try:
+            out["end_to_end"] = end_to_end_from_files(device, df, tmp, workers, batch, consumer_img_s)
+        except Exception as e:                                          # noqa: BLE001
+            out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
         # the reference's own host transform chain (float32 CHW out of __getitem__), per core, in this process: decode + Resize +
         # pad / crop / flip + ToTensor + Normalize
         ds_f = IMDBWIKI(df, tmp, img_size=224, split="train")
@@ -507,11 +535,71 @@ def input_pipeline_probe(device, consumer_img_s, batch=256, seconds=12.0, n_gpus
                                           "consumer_images_per_sec_per_gpu": consumer_img_s, "gpus": n_gpus_target,
                                           "verdict": "host-bound at 8 GPUs on this box" if n_gpus_target * consumer_img_s / per_core_dec > host_cores
                                                      else "the box's cores can feed 8 GPUs (decode-only workers, Resize + augmentation on the GPUs)"}
-        out["note"] = ("decode is host PIL in loader workers (no GPU JPEG decoder in this image), Resize either there or on the GPU; the rates are the loaders' own, not "
-                       "overlapped with training; `value` of this bench uses HBM-resident synthetic batches")
+        out["note"] = ("decode is host PIL in loader workers (no GPU JPEG decoder in this image), Resize either there or on the GPU; the two loader rates are the "
+                       "loaders' own; `end_to_end` trains from the files (loader, device transforms and the training loop running concurrently); `value` of this "
+                       "bench uses HBM-resident synthetic batches")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s, steps=48, epoch_len=8):
+    """datasets.py:38-53 + train.py:246-250, 269-281 with the files as the source: the product's --gpu_resize configuration (train_main.py)."""
+    from torch.utils.data import DataLoader, RandomSampler
+    from dirhip.datasets import IMDBWIKI, DeviceAugment, DeviceResize, ragged_collate
+    from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
+
+    class A:
+        pass
+    a = A()
+    a.batch, a.epoch_len, a.gpus = batch, 1, 1
+    model, engine, optimizer, _ = build(a, device, 0)
+    loss_fn = resolve_loss("l1")
+    store = EpochFeatures(epoch_len * batch, 2048, device)
+    ds = IMDBWIKI(df, data_dir, img_size=224, split="train", reweight="sqrt_inv", lds=True, lds_kernel="gaussian", lds_ks=5, lds_sigma=2, raw="decoded")
+    n_img = (2 * (steps + 2 * epoch_len) + 8) * batch
+
+    def loader():
+        return iter(DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds, replacement=True, num_samples=n_img), num_workers=workers, pin_memory=False,
+                               drop_last=True, prefetch_factor=2, persistent_workers=False, collate_fn=ragged_collate))
+    aug, rz = DeviceAugment(224, train=True, dtype=torch.bfloat16), DeviceResize(224, device)
+    stall = [0.0, 0]
+
+    def fetch(it):
+        t0 = time.perf_counter()
+        b = next(it)
+        stall[0] += time.perf_counter() - t0
+        stall[1] += 1
+        x = aug(rz(b[0], b[1]))
+        return x, b[2].to(device, non_blocking=True), b[3].to(device, non_blocking=True)
+
+    def run(n, it_train, it_tail, epoch):
+        for s0 in range(0, n, epoch_len):
+            k = min(epoch_len, n - s0)
+            for _ in range(k):
+                x, y, w = fetch(it_train)
+                train_step(engine, optimizer, x, y, w, epoch, loss_fn)
+            epoch_tail(engine, (fetch(it_tail)[:2] for _ in range(k)), epoch, store)
+            epoch += 1
+        return epoch
+    it_a, it_b = loader(), loader()
+    epoch = run(epoch_len, it_a, it_b, 2)                              # worker start-up, first-use costs of the device path, one epoch tail
+    torch.cuda.synchronize(device)
+    stall[0], stall[1] = 0.0, 0
+    t0 = time.perf_counter()
+    run(steps, it_a, it_b, epoch)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    del it_a, it_b
+    rate = steps * batch / dt
+    res = {"images_per_sec": rate, "ms_per_step": dt / steps * 1e3, "steps": steps, "tail_forward_batches": steps, "batch": batch,
+           "loader_blocked_ms_per_fetch": stall[0] / max(1, stall[1]) * 1e3, "loader_fetches": stall[1],
+           "synthetic_images_per_sec": synthetic_img_s, "ratio_to_synthetic": rate / synthetic_img_s,
+           "what": "JPEG files -> DataLoader workers (PIL decode only, ragged pageable batches) -> H2D -> dir_resize_u8 -> dir_augment_u8 (bf16 NHWC) -> "
+                   "train_step; the epoch-tail forward reads a second pass of the loader: two loader batches per trained batch, like the reference's loop"}
+    del engine, optimizer, model, store
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(seconds_budget=20.0):

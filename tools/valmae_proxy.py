@@ -10,7 +10,18 @@ AgeDB-DIR train histogram (tests/golden/lds_weights.npz: in_labels_agedb), valid
 reference's curated val sets are). ResNet-50 + LDS (sqrt_inv, gaussian 5/2) + FDS (agedb defaults), l1 loss, Adam 1e-3, the drop-in
 train_step / epoch_tail / validate / shot_metrics. For every seed the two modes share the initial weights and the batch order.
 
-    python tools/valmae_proxy.py [seeds=5] [epochs=4] [n_train=8192] [batch=64] [lr decay at epoch, 0 = none]   ->  gpurun_out/valmae_proxy.json (commit as profiles/rNN_valmae_proxy.json)"""
+Round 5: arms instead of two modes — ``bf16`` (the product path), ``float32`` (the product's parity-exact mode), ``lib_f32`` (the
+reference's own arithmetic on this GPU: the same network as plain torch modules on the vendor library's float32 kernels — tools/library_resnet.py)
+and ``lib_bf16`` (that network under ``torch.autocast(bfloat16)``: bf16 in general, not this repo's graph); every arm shares FDS / LDS / loss /
+Adam arithmetic, the initial weights and the batch order per seed. Deltas are paired against ``--ref`` (default lib_f32).
+``--branch E0``: variance-reduced form — ONE run of the reference arm up to epoch E0 is the common starting point (weights, BatchNorm and FDS
+buffers, Adam moments); every arm then trains the remaining epochs from it with the same batch order per seed, so the arms differ by their
+arithmetic over the converging phase only and the paired difference is not buried under the chaotic divergence of whole trajectories.
+
+    python tools/valmae_proxy.py --seeds 10 --epochs 24 --decay-at 16 --batch 256 --arms bf16,lib_f32,lib_bf16 [--branch 16] [--out name]
+    ->  gpurun_out/<name>.json (commit as profiles/rNN_<name>.json)"""
+import argparse
+import copy
 import json
 import os
 import sys
@@ -23,6 +34,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def make_task(device, n_train, n_val, seed=1234):
@@ -51,36 +63,63 @@ def make_task(device, n_train, n_val, seed=1234):
     return y_train, y_val, images(y_train, seed + 1), images(y_val, seed + 2)
 
 
-def run_one(mode, seed, task, epochs, batch, device, decay_at=0):
-    from dirhip import lds
+ARMS = ("bf16", "float32", "lib_f32", "lib_bf16")
+
+
+def build_arm(arm, seed, device, init_state=None):
+    """Model wrapper (call / .module / .parameters / .train / .eval) + optimizer for one arm; identical initial weights per seed."""
     from dirhip.optim import Adam
     from dirhip.parallel import DataParallelEngine
     from dirhip.resnet import resnet50
-    from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
-    from dirhip.train_main import shot_metrics, validate
-    y_train, y_val, x_train, x_val = task
     torch.manual_seed(seed)
     model = resnet50(fds=True, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
-    eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if mode == "bf16" else None, channels_last=True)
-    opt = Adam(eng.parameters(), lr=1e-3)
+    if init_state is not None:
+        model.load_state_dict(init_state["model"])
+    if arm in ("bf16", "float32"):
+        eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if arm == "bf16" else None, channels_last=True)
+        opt = Adam(eng.parameters(), lr=1e-3)
+    else:
+        from library_resnet import AutocastModel, LibraryResNet50
+        lib = LibraryResNet50(fds=model.FDS).to(device)
+        lib.load_state_dict(model.state_dict())                          # same weights, BatchNorm and FDS buffers
+        lib.to(memory_format=torch.channels_last)
+        eng = AutocastModel(lib, torch.bfloat16 if arm == "lib_bf16" else None)
+        opt = torch.optim.Adam(eng.parameters(), lr=1e-3)                  # (dirhip.optim.Adam is bit-equal to it: tests/test_hip_optim.py)
+    if init_state is not None and init_state.get("optimizer") is not None:
+        opt.load_state_dict(init_state["optimizer"])
+    return eng, opt
+
+
+def train_epochs(eng, opt, task, seed, epoch0, epochs, batch, decay_at, lr0=1e-3):
+    from dirhip import lds
+    from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
+    y_train, y_val, x_train, x_val = task
+    device = x_train.device
     w_all = torch.as_tensor(np.asarray(lds.prepare_weights(y_train, "sqrt_inv", lds=True, lds_kernel="gaussian", lds_ks=5, lds_sigma=2), dtype=np.float32),
                             device=device).view(-1, 1)
     yt = torch.as_tensor(y_train, device=device).view(-1, 1)
-    yv = torch.as_tensor(y_val, device=device).view(-1, 1)
     loss_fn = resolve_loss("l1")
     n = len(y_train)
     store = EpochFeatures(n, 2048, device)
     order_gen = torch.Generator().manual_seed(10_000 + seed)
     for epoch in range(epochs):
-        if decay_at and epoch == decay_at:                            # the reference's step schedule (train.py: adjust_learning_rate, x0.1), once
-            for gp in opt.param_groups:
-                gp["lr"] = gp["lr"] * 0.1
+        perm = torch.randperm(n, generator=order_gen).to(device)          # (drawn for every epoch, also the skipped ones: the order of epoch e is the same in every form)
+        if epoch < epoch0:
+            continue
+        for gp in opt.param_groups:                                       # the reference's step schedule (train.py: adjust_learning_rate, x0.1), once
+            gp["lr"] = lr0 * (0.1 if (decay_at and epoch >= decay_at) else 1.0)
         eng.train()
-        perm = torch.randperm(n, generator=order_gen).to(device)
         idx = [perm[s:s + batch] for s in range(0, n - batch + 1, batch)]
         for ix in idx:
             train_step(eng, opt, x_train[ix], yt[ix], w_all[ix], epoch, loss_fn)
         epoch_tail(eng, ((x_train[ix], yt[ix]) for ix in idx), epoch, store)
+
+
+def evaluate(eng, task, batch):
+    from dirhip.train_main import shot_metrics, validate
+    y_train, y_val, x_train, x_val = task
+    device = x_val.device
+    yv = torch.as_tensor(y_val, device=device).view(-1, 1)
 
     def val_batches():
         for s in range(0, len(y_val), batch):
@@ -95,48 +134,87 @@ def run_one(mode, seed, task, epochs, batch, device, decay_at=0):
             "few": float(shots["low"]["l1"])}
 
 
+def snapshot(eng, opt):
+    mod = eng.module
+    return {"model": {k: v.detach().clone() for k, v in mod.state_dict().items()}, "optimizer": copy.deepcopy(opt.state_dict())}
+
+
 def main():
-    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    n_train = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
-    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 64
-    decay_at = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--epochs", type=int, default=12)
+    ap.add_argument("--decay-at", type=int, default=8)
+    ap.add_argument("--n-train", type=int, default=8192)
+    ap.add_argument("--n-val", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--arms", default="bf16,lib_f32,lib_bf16")
+    ap.add_argument("--ref", default="lib_f32")
+    ap.add_argument("--branch", type=int, default=0, help="epoch at which the arms branch off ONE run of the reference arm (0 = whole schedules)")
+    ap.add_argument("--out", default="valmae_proxy")
+    a = ap.parse_args()
+    arms = [x for x in a.arms.split(",") if x]
+    assert all(x in ARMS for x in arms) and a.ref in arms
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
-    task = make_task(device, n_train, 2048)
-    res = {"bf16": [], "float32": []}
+    task = make_task(device, a.n_train, a.n_val)
+    res = {x: [] for x in arms}
     t0 = time.time()
-    for seed in range(seeds):
-        for mode in ("bf16", "float32"):
+    start = None
+    if a.branch:
+        eng, opt = build_arm(a.ref, 1000, device)
+        train_epochs(eng, opt, task, 1000, 0, a.branch, a.batch, a.decay_at)
+        start = snapshot(eng, opt)
+        start["metrics_at_branch"] = evaluate(eng, task, a.batch)
+        print(f"common start ({a.ref}, {a.branch} epochs): {start['metrics_at_branch']}", flush=True)
+        del eng, opt
+    for seed in range(a.seed0, a.seed0 + a.seeds):
+        for arm in arms:
             t1 = time.time()
-            r = run_one(mode, seed, task, epochs, batch, device, decay_at)
+            eng, opt = build_arm(arm, seed if not a.branch else 1000, device, init_state=start)
+            train_epochs(eng, opt, task, seed, a.branch, a.epochs, a.batch, a.decay_at)
+            r = evaluate(eng, task, a.batch)
             r["seconds"] = time.time() - t1
-            res[mode].append(r)
-            print(f"seed {seed} {mode}: {r}", flush=True)
+            res[arm].append(r)
+            print(f"seed {seed} {arm}: {r}", flush=True)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", a.out + ".partial.json"), "w") as f:     # (a run cut short still leaves its seeds)
+                json.dump({"args": vars(a), "per_seed": res}, f)
+            del eng, opt
+            torch.cuda.empty_cache()
+    keys = ("all", "many", "med", "few")
     out = {"task": "synthetic teacher task (tools/valmae_proxy.py): 224x224 images = fixed random low-resolution patterns with age-dependent coefficients + N(0,1) noise; "
-                   f"{n_train} train labels from the AgeDB-DIR train histogram (long-tailed), 2048 balanced validation labels; ResNet-50 + LDS + FDS, l1, Adam 1e-3, "
-                   f"batch {batch}, {epochs} epochs" + (f" (lr x0.1 from epoch {decay_at})" if decay_at else "") + ", the drop-in train_step / epoch_tail / validate / shot_metrics",
-           "seeds": seeds, "per_seed": res, "metric": "validation L1 (= val MAE, years): all / many-shot / median-shot / few-shot (train.py:286-391)"}
-    summ = {}
-    for mode, rows in res.items():
-        summ[mode] = {k: {"mean": float(np.mean([r[k] for r in rows])), "std": float(np.std([r[k] for r in rows], ddof=1)) if len(rows) > 1 else 0.0}
-                      for k in ("all", "many", "med", "few")}
-    out["summary"] = summ
-    d = {k: summ["bf16"][k]["mean"] - summ["float32"][k]["mean"] for k in ("all", "many", "med", "few")}
-    sig = {k: float(np.sqrt((summ["bf16"][k]["std"] ** 2 + summ["float32"][k]["std"] ** 2) / 2)) for k in d}
-    paired = np.array([a["all"] - b["all"] for a, b in zip(res["bf16"], res["float32"])])
-    out["delta_mean_bf16_minus_float32"] = d
-    out["seed_sigma"] = sig
-    out["paired_delta_all"] = {"mean": float(paired.mean()), "std": float(paired.std(ddof=1)) if len(paired) > 1 else 0.0,
-                               "stderr": float(paired.std(ddof=1) / np.sqrt(len(paired))) if len(paired) > 1 else 0.0}
-    out["statement"] = {k: ("|delta mean| <= 0.02" if abs(d[k]) <= 0.02 else
-                            ("inside one seed-sigma" if abs(d[k]) <= sig[k] else "OUTSIDE one seed-sigma")) + f" (delta {d[k]:+.4f}, seed sigma {sig[k]:.4f})"
-                        for k in d}
+                   f"{a.n_train} train labels from the AgeDB-DIR train histogram (long-tailed), {a.n_val} balanced validation labels; ResNet-50 + LDS + FDS, l1, Adam 1e-3, "
+                   f"batch {a.batch}, {a.epochs} epochs" + (f" (lr x0.1 from epoch {a.decay_at})" if a.decay_at else "") + ", the drop-in train_step / epoch_tail / validate / shot_metrics",
+           "arms": {"bf16": "the product path (this repo's bf16 graph)", "float32": "the product's parity-exact float32 mode",
+                    "lib_f32": "the reference's arithmetic on this GPU: plain torch modules, vendor-library float32 kernels (tools/library_resnet.py)",
+                    "lib_bf16": "the same library network under torch.autocast(bfloat16)"},
+           "form": (f"branch: every arm continues ONE {a.ref} run from epoch {a.branch} (weights, buffers, Adam moments), same batch order per seed" if a.branch
+                    else "whole schedules, same initial weights and batch order per seed"),
+           "seeds": a.seeds, "seed0": a.seed0, "reference_arm": a.ref, "per_seed": res,
+           "metric": "validation L1 (= val MAE, years): all / many-shot / median-shot / few-shot (train.py:286-391)"}
+    if start is not None:
+        out["metrics_at_branch"] = start["metrics_at_branch"]
+    out["summary"] = {arm: {k: {"mean": float(np.mean([r[k] for r in rows])), "std": float(np.std([r[k] for r in rows], ddof=1)) if len(rows) > 1 else 0.0}
+                            for k in keys} for arm, rows in res.items()}
+    out["paired_delta_vs_reference"] = {}
+    for arm in arms:
+        if arm == a.ref:
+            continue
+        d = {}
+        for k in keys:
+            v = np.array([x[k] - y[k] for x, y in zip(res[arm], res[a.ref])])
+            d[k] = {"mean": float(v.mean()), "std": float(v.std(ddof=1)) if len(v) > 1 else 0.0, "stderr": float(v.std(ddof=1) / np.sqrt(len(v))) if len(v) > 1 else 0.0}
+        out["paired_delta_vs_reference"][arm] = d
+    if "bf16" in arms and "lib_bf16" in arms:
+        v = np.array([x["all"] - y["all"] for x, y in zip(res["bf16"], res["lib_bf16"])])
+        out["paired_delta_bf16_minus_lib_bf16_all"] = {"mean": float(v.mean()), "std": float(v.std(ddof=1)) if len(v) > 1 else 0.0,
+                                                       "stderr": float(v.std(ddof=1) / np.sqrt(len(v))) if len(v) > 1 else 0.0}
     out["wall_seconds"] = time.time() - t0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "valmae_proxy.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", a.out + ".json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps({k: out[k] for k in ("summary", "delta_mean_bf16_minus_float32", "seed_sigma", "paired_delta_all", "statement", "wall_seconds")}, indent=1))
+    print(json.dumps({k: out[k] for k in out if k not in ("per_seed", "task", "arms")}, indent=1))
 
 
 if __name__ == "__main__":
