@@ -482,6 +482,41 @@ conv_wgrad_reduce_kernel(const float* __restrict__ part, int splits, size_t n, f
     }
 }
 
+// The same reduction for MANY layers in one launch (blockIdx.y = layer; row of the table = 4 int64: partials, splits, n, dw): the 52 per-layer
+// launches of a backward pass (5-8 us each, 0.4 ms per step) become one at its end. Every element is summed exactly as above (split lane sl takes
+// splits sl, sl + 16, ...; the lanes are combined in lane order): bit-identical to the per-layer kernel.
+__global__ void __launch_bounds__(DIR_TPB)
+conv_wgrad_reduce_batched_kernel(const long long* __restrict__ table) {
+    __shared__ float4 sh[RD_LANES][RD_COLS];
+    const long long* e = table + (size_t)blockIdx.y * 4;
+    const float* __restrict__ part = reinterpret_cast<const float*>(e[0]);
+    const int splits = (int)e[1];
+    const size_t n = (size_t)e[2];
+    float* __restrict__ dw = reinterpret_cast<float*>(e[3]);
+    const int col = threadIdx.x % RD_COLS, sl = threadIdx.x / RD_COLS;
+    const size_t groups = (n / 4 + RD_COLS - 1) / RD_COLS;
+    for (size_t gi = blockIdx.x; gi < groups; gi += gridDim.x) {     // (block-uniform trip count: the barriers below are safe)
+        const size_t i = (gi * RD_COLS + col) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+#pragma unroll 4
+            for (int k = sl; k < splits; k += RD_LANES) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        sh[sl][col] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            float4 t = sh[0][col];
+#pragma unroll
+            for (int k = 1; k < RD_LANES; ++k) { const float4 v = sh[k][col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(dw + i) = t;
+        }
+        __syncthreads();
+    }
+}
+
 struct WgPlan { int tm, tn, tiles_m, tiles_n, splits, ksteps_total, ksteps_per_split; size_t ws_bytes; int dma1; };
 
 // dma1: the register-lean 1x1 form (conv_wgrad1_dma_kernel): 0 = the transposing kernel, 1 = one stage / four workgroups per CU,
@@ -547,14 +582,23 @@ extern "C" size_t dir_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cou
     return wg_plan((long long)N * Ho * Wo, Cin, Cout, R * S, dma1).ws_bytes;
 }
 
-extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                              int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
-                              dir_stream_t stream) {
-    DIR_RETURN_IF(!dy || !x || !dw || !workspace, DIR_EINVAL);
+// table: device [nlayers][4] int64 = (partials [splits][n] float32, splits, n (% 4 == 0), dw [n] float32) per layer
+extern "C" int dir_conv_wgrad_reduce_batched(const void* table, int nlayers, dir_stream_t stream) {
+    DIR_RETURN_IF(!table || nlayers <= 0 || nlayers > 65535, DIR_EINVAL);
+    hipLaunchKernelGGL(conv_wgrad_reduce_batched_kernel, dim3(512, nlayers), dim3(DIR_TPB), 0, dir_s(stream), static_cast<const long long*>(table));
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// dw == nullptr: the split-K partials stay in `workspace` ([splits][Cout * R * S * Cin] float32 from its start) for a later reduction
+static int wgrad_impl(const void* dy, const void* x, float* dw, int* splits_out, int N, int H, int W, int Cin, int Cout,
+                      int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
+                      dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !x || !workspace, DIR_EINVAL);
     DIR_RETURN_IF(form < DIR_WGRAD_AUTO || form > DIR_WGRAD_DMA2, DIR_EINVAL);
     DIR_RETURN_IF(N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0, DIR_EINVAL);
     DIR_RETURN_IF(Cin % 64 != 0 || Cout % 64 != 0, DIR_EUNSUPPORTED);
-    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || !dir_aligned16(dw) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
+    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || (dw && !dir_aligned16(dw)) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     DIR_RETURN_IF(Ho <= 0 || Wo <= 0, DIR_EINVAL);
     const long long M = (long long)N * Ho * Wo;
@@ -591,8 +635,24 @@ extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
     else if (pl.tn == 128) wg_launch<64, 128>(p, nblocks, s);
     else wg_launch<64, 64>(p, nblocks, s);
     DIR_LAUNCH_CHECK();
+    if (splits_out) *splits_out = pl.splits;
+    if (!dw) return DIR_OK;
     const size_t n = (size_t)Cout * p.RS * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(dir_cdiv((long long)n / 4, RD_COLS)), dim3(DIR_TPB), 0, s, p.part, pl.splits, n, dw);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
+}
+
+extern "C" int dir_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                              int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
+                              dir_stream_t stream) {
+    DIR_RETURN_IF(!dw, DIR_EINVAL);
+    return wgrad_impl(dy, x, dw, nullptr, N, H, W, Cin, Cout, R, S, stride, pad, form, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_conv_wgrad_partials(const void* dy, const void* x, int* splits, int N, int H, int W, int Cin, int Cout,
+                                       int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes,
+                                       dir_stream_t stream) {
+    DIR_RETURN_IF(!splits, DIR_EINVAL);
+    return wgrad_impl(dy, x, nullptr, splits, N, H, W, Cin, Cout, R, S, stride, pad, form, workspace, workspace_bytes, stream);
 }

@@ -271,11 +271,11 @@ extern "C" size_t dir_conv_wgrad3x3_workspace(int N, int H, int W, int Cin, int 
     return w3_plan(N, W, Cin, Cout).ws_bytes;
 }
 
-extern "C" int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                                 void* workspace, size_t workspace_bytes, dir_stream_t stream) {
-    DIR_RETURN_IF(!dy || !x || !dw || !workspace, DIR_EINVAL);
+static int wgrad3_impl(const void* dy, const void* x, float* dw, int* splits_out, int N, int H, int W, int Cin, int Cout,
+                       void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dy || !x || !workspace, DIR_EINVAL);
     DIR_RETURN_IF(!w3_shape_ok(N, H, W, Cin, Cout, 3, 3, 1, 1), DIR_EUNSUPPORTED);
-    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || !dir_aligned16(dw) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
+    DIR_RETURN_IF(!dir_aligned16(dy) || !dir_aligned16(x) || (dw && !dir_aligned16(dw)) || (reinterpret_cast<uintptr_t>(workspace) & 255u), DIR_EINVAL);
     const W3Plan pl = w3_plan(N, W, Cin, Cout);
     DIR_RETURN_IF(workspace_bytes < pl.ws_bytes, DIR_EWORKSPACE);
     Wg3P p;
@@ -288,5 +288,19 @@ extern "C" int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N
     else if (W == 14) w3_launch<14>(p, s);
     else w3_launch<7>(p, s);
     DIR_LAUNCH_CHECK();
+    if (splits_out) *splits_out = pl.nsplit;
+    if (!dw) return DIR_OK;                                              // partials [nsplit][Cout * 9 * Cin] stay in the workspace
     return dir_conv_wgrad_reduce_splits(p.part, pl.nsplit, (size_t)Cout * 9 * Cin, dw, stream);
+}
+
+extern "C" int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                                 void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!dw, DIR_EINVAL);
+    return wgrad3_impl(dy, x, dw, nullptr, N, H, W, Cin, Cout, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_conv_wgrad3x3_partials(const void* dy, const void* x, int* splits, int N, int H, int W, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    DIR_RETURN_IF(!splits, DIR_EINVAL);
+    return wgrad3_impl(dy, x, nullptr, splits, N, H, W, Cin, Cout, workspace, workspace_bytes, stream);
 }

@@ -87,6 +87,9 @@ SIGNATURES = {
     "dir_conv_wgrad3x3_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dir_conv_wgrad3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_conv_wgrad_reduce_splits": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
+    "dir_conv_wgrad_partials": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    "dir_conv_wgrad3x3_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_conv_wgrad_reduce_batched": (c_int, [c_void_p, c_int, c_void_p]),
     "dir_augment_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_resize_ksize": (c_int, [c_int, c_int]),
     "dir_resize_u8_workspace": (c_size_t, [c_int, c_int, c_int, c_size_t]),

@@ -183,6 +183,65 @@ def _wgrad_side_done(device, side, *operands):
         _WGRAD_SIDE["task"] = task
 
 
+# ONE split-K reduction launch per backward pass (round 5): inside a backward pass a weight-gradient node whose output is a gradient-bucket
+# slot (gradsink: persistent storage that autograd adopts as ``param.grad`` by reference) runs only the split-K GEMM, leaves its partials in
+# a workspace that persists per layer, and the reduction of ALL such layers is one launch in an autograd end-of-pass callback
+# (``dir_conv_wgrad_reduce_batched``: same order per element, bit-identical): 52 launches of 5-8 us per ResNet-50 step become one, and
+# ``.grad`` is complete when ``backward()`` returns, as before. Not taken — the per-layer reduction runs at once — outside a backward pass, for
+# ordinary (not bucket) outputs (autograd may add them into a held gradient immediately), on the side stream, and when the data-parallel
+# engine's collectives are live (their hooks fire per parameter, before the end of the pass): ``set_wgrad_batched_reduce(False)``.
+_WGRAD_BATCH = {"on": True, "pending": {}, "task": None, "ws": {}, "tables": {}}
+
+
+def set_wgrad_batched_reduce(enabled):
+    """Returns the previous setting. Turning it off reduces whatever is still pending."""
+    prev = _WGRAD_BATCH["on"]
+    _WGRAD_BATCH["on"] = bool(enabled)
+    if prev and not enabled:
+        wgrad_flush()
+    return prev
+
+
+def wgrad_flush():
+    """Reduce the pending split-K partials of every device (one launch each) on the device's current stream."""
+    st = _WGRAD_BATCH
+    st["task"] = None
+    for idx, rows in st["pending"].items():
+        if not rows:
+            continue
+        key = tuple(rows)
+        tab = st["tables"].get(idx)
+        if tab is None or tab[0] != key:                          # static after the first step: persistent workspaces and bucket slots
+            tab = (key, torch.tensor(rows, dtype=torch.int64).to(torch.device("cuda", idx)))
+            st["tables"][idx] = tab
+        rows.clear()
+        L.check(L.lib().dir_conv_wgrad_reduce_batched(L.ptr(tab[1]), len(key), L.stream_ptr(torch.device("cuda", idx))), "dir_conv_wgrad_reduce_batched")
+
+
+def _wgrad_batch_slot(dw, from_sink, nbytes):
+    """The persistent workspace for this layer when its reduction can wait for the end of the backward pass, else None."""
+    st = _WGRAD_BATCH
+    if not (st["on"] and from_sink and dw.is_cuda and not _WGRAD_SIDE["on"]):
+        return None
+    task = torch._C._current_graph_task_id()
+    if task == -1:
+        return None
+    idx = dw.device.index if dw.device.index is not None else torch.cuda.current_device()
+    rows = st["pending"].setdefault(idx, [])
+    if any(r[3] == dw.data_ptr() for r in rows):                 # the same gradient twice in one pass (shared weights): not batched
+        return None
+    if st["task"] != task:
+        if st["task"] is not None and any(st["pending"].values()):
+            wgrad_flush()                                         # (a pass that ended without its callback: nothing may linger)
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
+        st["task"] = task
+    key = (idx, dw.data_ptr())
+    ws = st["ws"].get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = st["ws"][key] = torch.empty(nbytes, dtype=torch.uint8, device=dw.device)
+    return ws
+
+
 def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None, form=L.WGRAD_AUTO):
     """Weight gradient (float32, channels_last ``[Cout, Cin, R, S]``) from bf16 channels_last ``dy`` and ``x``. ``sink``: the
     parameter's gradient-bucket factory (``gradsink.lookup``): the kernel then writes into the data-parallel bucket. ``form``:
@@ -193,34 +252,54 @@ def conv2d_wgrad(dy, x, kernel_size, stride=1, padding=0, sink=None, form=L.WGRA
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     cout, cin = dy.shape[1], x.shape[1]
-    dw = gradsink.out_for(sink, (cout, cin, kernel_size, kernel_size), x.device, torch.channels_last)
+    dw, from_sink = gradsink.out_for_ex(sink, (cout, cin, kernel_size, kernel_size), x.device, torch.channels_last)
     side = _wgrad_side(x.device)
     if side is None:
-        _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form)
+        _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form, from_sink)
     else:
         with torch.cuda.stream(side):
-            _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form)
+            _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form, False)
         _wgrad_side_done(x.device, side, dy, x)
     return dw
 
 
-def _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form=L.WGRAD_AUTO):
+def _wgrad_launch(dy, x, dw, kernel_size, stride, padding, form=L.WGRAD_AUTO, from_sink=False):
+    import ctypes
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     r = s = kernel_size
+    lib = L.lib()
+
+    def pend(ws, splits):
+        idx = dw.device.index if dw.device.index is not None else torch.cuda.current_device()
+        _WGRAD_BATCH["pending"][idx].append((ws.data_ptr(), int(splits.value), cout * r * s * cin, dw.data_ptr()))
     if kernel_size == 3 and stride == 1 and padding == 1 and _WGRAD3_ALL_TAPS[0]:
-        nbytes = L.lib().dir_conv_wgrad3x3_workspace(n, h, w, cin, cout)
+        nbytes = lib.dir_conv_wgrad3x3_workspace(n, h, w, cin, cout)
         if nbytes:
+            ws = _wgrad_batch_slot(dw, from_sink, nbytes)
+            if ws is not None:
+                splits = ctypes.c_int(0)
+                L.check(lib.dir_conv_wgrad3x3_partials(L.ptr(dy), L.ptr(x), ctypes.addressof(splits), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
+                                                       L.stream_ptr(x.device)), "dir_conv_wgrad3x3_partials")
+                pend(ws, splits)
+                return
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            L.check(L.lib().dir_conv_wgrad3x3(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
-                                              L.stream_ptr(x.device)), "dir_conv_wgrad3x3")
+            L.check(lib.dir_conv_wgrad3x3(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, L.ptr(ws), ws.numel(),
+                                          L.stream_ptr(x.device)), "dir_conv_wgrad3x3")
             return
-    nbytes = L.lib().dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding, form)
+    nbytes = lib.dir_conv_wgrad_workspace(n, h, w, cin, cout, r, s, stride, padding, form)
     if nbytes == 0:
         raise L.DirHipError(f"dir_conv_wgrad: unsupported shape Cin={cin} Cout={cout} (form {form})")
+    ws = _wgrad_batch_slot(dw, from_sink, nbytes)
+    if ws is not None:
+        splits = ctypes.c_int(0)
+        L.check(lib.dir_conv_wgrad_partials(L.ptr(dy), L.ptr(x), ctypes.addressof(splits), n, h, w, cin, cout, r, s, stride, padding, form, L.ptr(ws),
+                                            ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad_partials")
+        pend(ws, splits)
+        return
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    L.check(L.lib().dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, form, L.ptr(ws),
-                                   ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
+    L.check(lib.dir_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, w, cin, cout, r, s, stride, padding, form, L.ptr(ws),
+                               ws.numel(), L.stream_ptr(x.device)), "dir_conv_wgrad")
 
 
 class _ConvFn(torch.autograd.Function):

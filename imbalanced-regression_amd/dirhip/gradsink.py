@@ -25,16 +25,22 @@ def lookup(param):
     return _SINKS.get(param.data_ptr()) if _SINKS else None
 
 
-def out_for(param_or_factory, shape, device, memory_format=torch.contiguous_format):
-    """Float32 output tensor of ``shape`` for the gradient of ``param``: its bucket slot when an engine registered one (and the
-    geometry matches), else a new tensor."""
+def out_for_ex(param_or_factory, shape, device, memory_format=torch.contiguous_format):
+    """``(tensor, from_sink)``: the float32 output tensor of ``shape`` for the gradient of ``param`` — its bucket slot when an engine
+    registered one (and the geometry matches; ``from_sink`` True: persistent storage that autograd adopts as ``param.grad``), else a new tensor."""
     f = param_or_factory if (param_or_factory is None or callable(param_or_factory)) else lookup(param_or_factory)
     if f is not None:
         v = f()
         if v is not None and v.device == device:
             if tuple(v.shape) == tuple(shape):
                 if memory_format == torch.contiguous_format or v.is_contiguous(memory_format=memory_format):
-                    return v
+                    return v, True
             elif v.numel() == int(torch.Size(shape).numel()) and v.is_contiguous():
-                return v.view(shape)
-    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=memory_format)
+                return v.view(shape), True
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=memory_format), False
+
+
+def out_for(param_or_factory, shape, device, memory_format=torch.contiguous_format):
+    """Float32 output tensor of ``shape`` for the gradient of ``param``: its bucket slot when an engine registered one (and the
+    geometry matches), else a new tensor."""
+    return out_for_ex(param_or_factory, shape, device, memory_format)[0]

@@ -92,6 +92,11 @@ class DataParallelEngine(nn.Module):
         # process group of ONE rank too — every collective then is the identity, which is how the RCCL path is executed and checked
         # on a one-GPU box (tests/test_hip_rccl.py); never set by the training entry points
         self._comm = bool(self.world > 1 or (force_collectives and dist.is_initialized()))
+        if self._comm:
+            # the bucket collectives start from per-parameter hooks, i.e. before the end of the backward pass: every weight gradient must be
+            # complete when its node returns — the one-launch-per-pass split-K reduction of conv.py is for the one-process loop
+            from . import conv as _conv
+            _conv.set_wgrad_batched_reduce(False)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last

@@ -421,6 +421,16 @@ int dir_conv_wgrad3x3(const void* dy, const void* x, float* dw, int N, int H, in
                       size_t workspace_bytes, dir_stream_t stream);
 /* dw[i] = sum over s < splits, in order, of part[s * n + i] (the reduction pass of both weight-gradient forms); n % 4 == 0. */
 int dir_conv_wgrad_reduce_splits(const float* part, int splits, size_t n, float* dw, dir_stream_t stream);
+/* Round 5: ONE reduction launch per backward pass instead of one per layer (52 launches of 5-8 us at ResNet-50).  The two *_partials entry
+ * points run the split-K GEMM of dir_conv_wgrad / dir_conv_wgrad3x3 only: the partials stay at the start of `workspace` as
+ * [*splits][Cout * R * S * Cin] float32 (the caller keeps the workspace alive).  dir_conv_wgrad_reduce_batched then sums the layers listed
+ * in `table` (device memory, [nlayers][4] int64 = partials, splits, n, dw) exactly as dir_conv_wgrad_reduce_splits does per layer — same
+ * order per element, bit-identical gradients (imdb-wiki-dir/train.py:260, loss.backward(): the weight half of every conv layer). */
+int dir_conv_wgrad_partials(const void* dy, const void* x, int* splits, int N, int H, int W, int Cin, int Cout,
+                            int R, int S, int stride, int pad, int form, void* workspace, size_t workspace_bytes, dir_stream_t stream);
+int dir_conv_wgrad3x3_partials(const void* dy, const void* x, int* splits, int N, int H, int W, int Cin, int Cout, void* workspace,
+                               size_t workspace_bytes, dir_stream_t stream);
+int dir_conv_wgrad_reduce_batched(const void* table, int nlayers, dir_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * §8f-4  training-time image augmentation on the GPU.  Replaces, for a decoded and resized uint8 batch, the transform chain
  * of imdb-wiki-dir/datasets.py:38-53 behind Resize: RandomCrop(S, padding = pad, fill 0) -> RandomHorizontalFlip ->

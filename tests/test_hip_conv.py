@@ -447,3 +447,50 @@ def test_stride2_3x3_data_gradient_by_parity_classes(shape):
     assert_close(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
     rel = ((conv.weight.grad - wr.grad).norm() / wr.grad.norm()).item()
     assert rel < 1e-2, rel
+
+
+def test_batched_weight_gradient_reduction_is_bit_identical_and_one_launch():
+    """Round 5: inside a backward pass the split-K partials of every convolution layer are reduced by ONE launch in an autograd end-of-pass
+    callback (dir_conv_wgrad_reduce_batched) instead of one launch per layer. Same gradients bit for bit as the per-layer form, `.grad`
+    complete when backward() returns, and the profiler sees one reduction kernel per step instead of 52."""
+    from torch.profiler import ProfilerActivity, profile
+    from dirhip import conv as C
+    from dirhip.parallel import DataParallelEngine
+    from dirhip.resnet import resnet50
+    from dirhip.train_loop import resolve_loss
+
+    def grads(batched):
+        prev = C.set_wgrad_batched_reduce(batched)
+        try:
+            torch.manual_seed(0)
+            model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).cuda()
+            eng = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
+            eng.train()
+            g = torch.Generator(device="cuda").manual_seed(1)
+            x = torch.randn(8, 3, 224, 224, device="cuda", generator=g)
+            y = torch.tensor([[25.0], [31.0], [64.0], [25.0]] * 2, device="cuda")
+            w = torch.ones(8, 1, device="cuda")
+            loss_fn = resolve_loss("l1")
+            out = []
+            names = []
+            for it in range(2):                               # second pass: cached table, persistent workspaces
+                eng.zero_grad(set_to_none=True)
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    loss = loss_fn(eng(x, y, 2)[0], y, w)
+                    loss.backward()
+                    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}      # read right after backward()
+                    torch.cuda.synchronize()
+                out.append(got)
+                names = [(e.key, e.count) for e in prof.key_averages()]
+            return out, names
+        finally:
+            C.set_wgrad_batched_reduce(prev)
+    a, names_a = grads(False)
+    b, names_b = grads(True)
+    for ga, gb in zip(a, b):
+        assert ga.keys() == gb.keys() and len(ga) == 161
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    per_layer = sum(c for k, c in names_a if "conv_wgrad_reduce_kernel" in k)
+    batched = sum(c for k, c in names_b if "conv_wgrad_reduce_batched_kernel" in k)
+    assert per_layer == 52 and batched == 1 and not any("conv_wgrad_reduce_kernel" in k for k, _ in names_b), (names_a, names_b)
