@@ -142,3 +142,35 @@ def test_device_augment_feeds_the_network():
         a = model(x32)
         b = model(x16)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.gpu
+def test_device_image_cache_serves_the_stored_bytes_with_fresh_augmentation():
+    """datasets.DeviceImageCache: what put() stored is what batches() augments — every sample of the shard exactly once per pass, labels and
+    weights travelling with their images, `covers` true only once every requested sample is in."""
+    import torch
+    from dirhip.datasets import DeviceAugment, DeviceImageCache
+    dev = torch.device("cuda", 0)
+    n, s = 40, 32
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randint(0, 256, (n, s, s, 3), dtype=torch.uint8, generator=g)
+    labels = torch.arange(n, dtype=torch.float32).view(-1, 1)
+    weights = (torch.arange(n, dtype=torch.float32) * 0.5 + 1).view(-1, 1)
+    cache = DeviceImageCache(n, s, dev)
+    idx_a = torch.tensor([3, 7, 1, 39, 20])
+    assert not cache.covers(idx_a)
+    cache.put(idx_a, imgs[idx_a].to(dev), labels[idx_a].to(dev), weights[idx_a].to(dev))
+    assert cache.covers(idx_a) and not cache.covers(torch.arange(n))
+    rest = torch.tensor([i for i in range(n) if i not in set(idx_a.tolist())])
+    cache.put(rest, imgs[rest].to(dev), labels[rest].to(dev), weights[rest].to(dev))
+    assert cache.covers(torch.arange(n))
+    aug = DeviceAugment(s, train=False, dtype=torch.float32)        # eval transform: deterministic, so the pixels can be compared
+    shard = torch.tensor([5, 6, 7, 8, 9, 30, 31, 2, 0, 39, 17])
+    seen = []
+    for x, y, w, valid in cache.batches(shard, 4, aug, valid=[True] * 10 + [False]):
+        ids = y.view(-1).long().cpu()
+        seen += ids.tolist()
+        assert torch.equal(w.cpu().view(-1), weights[ids].view(-1)) and valid.dtype == torch.bool and len(valid) == len(ids)
+        want = aug(imgs[ids].to(dev))
+        assert torch.equal(x, want)
+    assert sorted(seen) == sorted(shard.tolist())

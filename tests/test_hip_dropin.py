@@ -67,7 +67,8 @@ def test_train_py_cli_train_resume_evaluate(tmp_path):
 def test_train_py_cli_on_image_files_host_and_gpu_augment(tmp_path):
     """The real-data path of the drop-in CLI, executed: an agedb-style csv + image files (written here), DataLoader workers, the
     host transform chain — the same run with --gpu_augment (uint8 batches, dir_augment_u8 on the GPU) — and with
-    --gpu_resize (workers only decode: ragged uint8 batches, dir_resize_u8 + dir_augment_u8 on the GPU)."""
+    --gpu_resize (workers only decode: ragged uint8 batches, dir_resize_u8 + dir_augment_u8 on the GPU), and with --gpu_cache on top (the
+    resized bytes stay in HBM: the feature pass of epoch 0 and all of epoch 1 run without the loader)."""
     import pandas as pd
     from PIL import Image
     rng = np.random.default_rng(0)
@@ -85,8 +86,10 @@ def test_train_py_cli_on_image_files_host_and_gpu_augment(tmp_path):
     base = ["--dataset", "agedb", "--data_dir", str(data), "--fds", "--lds", "--reweight", "sqrt_inv", "--batch_size", "32", "--epoch", "2",
             "--workers", "2", "--img_size", "224", "--print_freq", "1", "--bucket_start", "3"]
     losses = {}
-    for tag, extra in (("host", []), ("gpu", ["--gpu_augment"]), ("gpu_resize", ["--gpu_resize"])):
+    for tag, extra in (("host", []), ("gpu", ["--gpu_augment"]), ("gpu_resize", ["--gpu_resize"]), ("gpu_cache", ["--gpu_resize", "--gpu_cache"])):
         out = _cli(base + extra + ["--store_root", str(tmp_path / tag)], f"cli_files_{tag}.log")
+        if tag == "gpu_cache":
+            assert "Training images cached in HBM once decoded" in out
         for needle in ("Training data size: 150", "Validation data size: 12", "Create Epoch [1] features of all training data...",
                        "Updated smoothed statistics on Epoch [1]!", " * Overall: MSE", "Test loss: MSE"):
             assert needle in out, (tag, needle)

@@ -119,3 +119,30 @@ def test_training_step_has_no_library_gemv():
            and "maxpool" not in n and "avgpool" not in n]
     assert not [n for n in names if n.startswith("Cijk_") or "gemv" in n.lower() or "miopen" in n.lower()], bad
     assert any("tail_fwd_kernel" in n for n in names) and any("tail_bwd_dx_kernel" in n for n in names), names
+
+
+def test_no_grad_train_mode_forward_equals_the_grad_forward_bit_for_bit():
+    """The epoch-tail pass (train.py:269-281) is a train-mode forward under no_grad: it skips what only a backward needs (ReLU bit masks, the
+    stem tail's x[argmax], BatchNorm backward links) but must produce the SAME prediction, encoding and BatchNorm running statistics as the
+    forward of a training step on the same weights and batch."""
+    from dirhip.parallel import DataParallelEngine
+    from dirhip.resnet import resnet50
+
+    def run(no_grad):
+        torch.manual_seed(0)
+        model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).cuda()
+        eng = DataParallelEngine(model, amp_dtype=torch.bfloat16, channels_last=True)
+        eng.train()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(8, 3, 224, 224, device="cuda", generator=g)
+        y = torch.tensor([[25.0], [31.0], [64.0], [25.0]] * 2, device="cuda")
+        ctx = torch.no_grad() if no_grad else torch.enable_grad()
+        with ctx:
+            pred, enc = eng(x, y, 0)                          # (epoch 0 < start_smooth: the calibration is the identity in both)
+        torch.cuda.synchronize()
+        stats = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k and "FDS" not in k}
+        return pred.detach().clone(), enc.detach().clone(), stats
+    p0, e0, s0 = run(False)
+    p1, e1, s1 = run(True)
+    assert torch.equal(p0, p1) and torch.equal(e0, e1)
+    assert s0.keys() == s1.keys() and all(torch.equal(s0[k], s1[k]) for k in s0)
