@@ -1,6 +1,6 @@
 """In-process A/B of whole training steps (B=256, bf16 product path) with one switch flipped: alternating rounds of `steps`
 train steps each, wall clock per step. Switches: wgrad3 (conv.set_wgrad3_all_taps), bnfuse (resnet.set_bn_bwd_fusion),
-relubits (bn.set_relu_bits), joinbwd, wgradside, stemtail.   python tools/ab_train_step.py wgrad3 [rounds] [steps] [train|tail]"""
+relubits (bn.set_relu_bits), joinbwd, wgradside, stemtail, wgradbatch (conv.set_wgrad_batched_reduce).   python tools/ab_train_step.py wgrad3 [rounds] [steps] [train|tail]"""
 import os
 import sys
 import time
@@ -27,7 +27,7 @@ def main():
     # Python-level wiring switches only: the C-ABI has no process-wide kernel switches any more (kernel variants are per-launch arguments;
     # to A/B two builds of a kernel use tools/ab_two_libs.py)
     setter = {"joinbwd": B.set_join_bwd, "wgrad3": C.set_wgrad3_all_taps, "bnfuse": R.set_bn_bwd_fusion, "relubits": B.set_relu_bits,
-              "wgradside": C.set_wgrad_side_stream, "stemtail": P.set_stem_tail_xmax}[which]
+              "wgradside": C.set_wgrad_side_stream, "stemtail": P.set_stem_tail_xmax, "wgradbatch": C.set_wgrad_batched_reduce}[which]
 
     class A:
         batch, epoch_len, gpus = 256, 8, 1
