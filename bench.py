@@ -229,7 +229,7 @@ def measured_peaks(device):
     out["stream_write_GBs"] = nbytes / ms / 1e6
     # on-chip re-read rates with the latency covered (4 workgroups per CU, 8 x 16 B in flight per lane): a 2 MB region lives in
     # every XCD's 4 MB L2, a 32 MB one only in the 256 MB Infinity Cache. The convolution K loops move ~12 TB/s from the same
-    # levels: between the two, i.e. bound by bytes in flight x latency, not by the L2's bandwidth
+    # levels: between the two, i.e. bound by bytes in flight x latency, not by the L2's bandwidth (HISTORY.md §4)
     for key, region, passes in (("l2_resident_read_GBs", 2 << 20, 16), ("mall_resident_read_GBs", 32 << 20, 1)):
         ms = event_time_ms(lambda i: L.check(lib.dir_probe_l2_read(L.ptr(src), L.ptr(red), region, 1024, passes, 8, st), key), 5)
         out[key] = 1024 * passes * region / ms / 1e6
@@ -564,20 +564,28 @@ def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s,
     model, engine, optimizer, _ = build(a, device, 0)
     loss_fn = resolve_loss("l1")
     store = EpochFeatures(epoch_len * batch, 2048, device)
-    base = IMDBWIKI(df, data_dir, img_size=224, split="train", reweight="sqrt_inv", lds=True, lds_kernel="gaussian", lds_ks=5, lds_sigma=2, raw="decoded")
+    bases = {raw: IMDBWIKI(df, data_dir, img_size=224, split="train", reweight="sqrt_inv", lds=True, lds_kernel="gaussian", lds_ks=5, lds_sigma=2, raw=raw)
+             for raw in ("decoded", True)}
 
     class Indexed(Dataset):                                          # (+ the sample index: the key of the HBM cache, as train_main._ShardSubset)
+        def __init__(self, base):
+            self.base = base
+
         def __len__(self):
-            return len(base)
+            return len(self.base)
 
         def __getitem__(self, i):
-            return tuple(base[i]) + (int(i),)
-    ds = Indexed()
+            return tuple(self.base[i]) + (int(i),)
+    ds = Indexed(bases["decoded"])
     n_img = (2 * (cold_steps + 2 * epoch_len) + 8) * batch
 
-    def loader():
-        return iter(DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds, replacement=True, num_samples=n_img), num_workers=workers, pin_memory=False,
-                               drop_last=True, prefetch_factor=2, persistent_workers=False, collate_fn=ragged_collate))
+    def loader(raw="decoded"):
+        d = Indexed(bases[raw])
+        if raw == "decoded":
+            return iter(DataLoader(d, batch_size=batch, sampler=RandomSampler(d, replacement=True, num_samples=n_img), num_workers=workers, pin_memory=False,
+                                   drop_last=True, prefetch_factor=2, persistent_workers=False, collate_fn=ragged_collate))
+        return iter(DataLoader(d, batch_size=batch, sampler=RandomSampler(d, replacement=True, num_samples=n_img), num_workers=workers, pin_memory=True,
+                               drop_last=True, prefetch_factor=4, persistent_workers=False))
     aug = DeviceAugment(224, train=True, dtype=torch.bfloat16)
     cache = DeviceImageCache(len(ds), 224, device)
     stall = [0.0, 0]
@@ -588,8 +596,11 @@ def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s,
             return lambda b: (b[0][:16], b[2], b[3])
 
         def half(b):
-            u8, y, w = rz(b[0], b[1]), b[2].to(device, non_blocking=True), b[3].to(device, non_blocking=True)
-            cache.put(b[4], u8, y, w)
+            if rz is None:                                        # workers decoded AND resized: fixed-size pinned uint8 batches
+                u8, y, w, idx = b[0].to(device, non_blocking=True), b[1].to(device, non_blocking=True), b[2].to(device, non_blocking=True), b[3]
+            else:
+                u8, y, w, idx = rz(b[0], b[1]), b[2].to(device, non_blocking=True), b[3].to(device, non_blocking=True), b[4]
+            cache.put(idx, u8, y, w)
             return aug(u8), y, w
         return half
 
@@ -628,20 +639,26 @@ def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s,
     old_si = sys.getswitchinterval()
     if switch_interval:
         sys.setswitchinterval(switch_interval)
-    pf_a, pf_b = (DevicePrefetcher(loader(), device, device_half_of(DeviceResize(224, device, stager=PinnedStager() if pinned else None)), depth=depth)
-                  for _ in range(2))
-    it_a, it_b = iter(pf_a), iter(pf_b)
-    epoch = run(epoch_len, it_a, it_b, 2)                              # worker start-up, first-use costs of the device path, one epoch tail
-    epoch, cold = timed_run(cold_steps, it_a, it_b, epoch)
-    pf_a.close(); pf_b.close()
+    what = {"decoded": "JPEG files -> DataLoader workers (PIL decode only, ragged pageable batches of ~78 MB) -> datasets.DevicePrefetcher (thread + side stream: H2D -> "
+                       "dir_resize_u8 -> store in the HBM cache -> dir_augment_u8, bf16 NHWC) -> train_step; the epoch-tail forward reads a second pass of the loader: two "
+                       "decoded batches per trained batch. Bound by the loaders' hand-over of the ragged batches through shared memory; on the training stream instead of the "
+                       "prefetcher the same device half measured 4 814 img/s (a pageable copy is stream-ordered and blocks the host behind the queued step)",
+            True: "the same loop with the Resize in the workers (train.py --gpu_augment): half the bytes per batch, fixed-size pinned uint8 batches, 3.5 x the host work per image"}
+    res = {"batch": batch, "synthetic_images_per_sec": synthetic_img_s, "prefetch_depth": depth, "pinned_staging": bool(pinned), **({"diagnose": diagnose} if diagnose else {})}
+    epoch = 2
+    for raw, tag in (("decoded", "cold_decode_only_workers"), (True, "cold_decode_and_resize_in_workers")):
+        if diagnose and raw is True:
+            continue
+        pf_a, pf_b = (DevicePrefetcher(loader(raw), device, device_half_of(DeviceResize(224, device, stager=PinnedStager() if pinned else None) if raw == "decoded" else None),
+                                       depth=depth) for _ in range(2))
+        it_a, it_b = iter(pf_a), iter(pf_b)
+        epoch = run(epoch_len, it_a, it_b, epoch)                          # worker start-up, first-use costs of the device path, one epoch tail
+        epoch, cold = timed_run(cold_steps, it_a, it_b, epoch)
+        pf_a.close(); pf_b.close()
+        del it_a, it_b, pf_a, pf_b
+        res[tag] = dict(cold, workers_per_loader=workers, loaders=2, what=what[raw])
     sys.setswitchinterval(old_si)
-    del it_a, it_b, pf_a, pf_b
-    res = {"batch": batch, "synthetic_images_per_sec": synthetic_img_s, "prefetch_depth": depth, "pinned_staging": bool(pinned), **({"diagnose": diagnose} if diagnose else {}),
-           "cold_every_batch_through_the_loader": dict(cold, what="JPEG files -> DataLoader workers (PIL decode only, ragged pageable batches) -> datasets.DevicePrefetcher "
-                                                       "(thread + side stream: H2D -> dir_resize_u8 -> store in the HBM cache -> dir_augment_u8, bf16 NHWC) -> train_step; "
-                                                       "the epoch-tail forward reads a second pass of the loader: two decoded batches per trained batch. Bound by what the "
-                                                       "loaders deliver (two passes = 2 x the consumer's rate); on the training stream instead of the prefetcher the same "
-                                                       "device half measured 4 814 img/s (a pageable copy is stream-ordered and blocks the host behind the queued step)")}
+    cold = res["cold_decode_only_workers"]
     if not diagnose and cache.covers(np.arange(len(ds))):
         gen = torch.Generator().manual_seed(11)
         n_warm = epoch_len
@@ -1015,7 +1032,7 @@ def main():
             except Exception as e:                                      # noqa: BLE001
                 log(f"PMC traffic passes failed ({type(e).__name__}: {e}); quoting the committed pass")
         if traffic_note is None:
-            for name in ("r04_conv_pmc_traffic.json", "r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
+            for name in ("r05_conv_pmc_traffic.json", "r04_conv_pmc_traffic.json", "r02_conv_pmc_traffic.json", "r01_conv_pmc_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.isfile(tpath):
                     tj = json.load(open(tpath))
@@ -1024,7 +1041,7 @@ def main():
                                     "launches_per_step_in_that_pass": tj.get("launches_per_step")}
                     break
         mfma_busy = None
-        for name in ("r04_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+        for name in ("r05_conv_mfma_util.json", "r04_conv_mfma_util.json", "r02_conv_mfma_util.json"):
             mpath = os.path.join(ROOT, "profiles", name)
             if os.path.isfile(mpath):
                 mj = json.load(open(mpath))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 rocprofv3 evidence run (GPU box, repo root): kernel trace + stats of bench.py's train loop, per-step breakdown, and three separate
+# Round-5 rocprofv3 evidence run (GPU box, repo root): kernel trace + stats of bench.py's train loop, per-step breakdown, and three separate
 # --pmc passes over tools/pmc_conv_pass.py (MFMA busy cycles; FETCH_SIZE; WRITE_SIZE — counters only next to --kernel-trace).
-R=$(pwd); O=$R/gpurun_out/${1:-r04prof}; mkdir -p "$O"
+R=$(pwd); O=$R/gpurun_out/${1:-r05prof}; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o bench -- python "$R/bench.py" --steps 24 --warmup 8 --no-kernel-rooflines --no-cpu-baseline --no-input-pipeline --no-float32-mode > "$O/bench_under_rocprof.json" 2> "$O/bench_trace.err"
 KT=$(find "$O/trace" -name "*kernel_trace.csv" | head -1)
@@ -12,8 +12,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -o WRITE_SIZE -- python "$R/tools/pmc_conv_pass.py" 256 > "$O/pmc_write.log" 2>&1
 mkdir -p "$O/cc"; find "$O" -name "*counter_collection.csv" -exec cp {} "$O/cc/" \;
 cd "$R"
-python tools/pmc_mfma_parse.py "$O/cc/p_counter_collection.csv" r04_conv_mfma_util.json | tail -60 > "$O/mfma_util.txt"
-python tools/pmc_conv_parse.py "$O/cc" r04_conv_pmc_traffic.json | tail -14 > "$O/pmc_traffic.txt"
-cp profiles/r04_conv_mfma_util.json profiles/r04_conv_pmc_traffic.json "$O/"
+python tools/pmc_mfma_parse.py "$O/cc/p_counter_collection.csv" r05_conv_mfma_util.json | tail -60 > "$O/mfma_util.txt"
+python tools/pmc_conv_parse.py "$O/cc" r05_conv_pmc_traffic.json | tail -14 > "$O/pmc_traffic.txt"
+cp profiles/r05_conv_mfma_util.json profiles/r05_conv_pmc_traffic.json "$O/"
 find "$O" -name "*.db" -delete; find "$O" -name "*kernel_trace.csv" -delete; find "$O" -name "*counter_collection.csv" -size +20M -delete
 head -40 "$O/train_step_breakdown.txt"; head -8 "$O/mfma_util.txt"; du -sh "$O"
