@@ -183,14 +183,17 @@ def _wgrad_side_done(device, side, *operands):
         _WGRAD_SIDE["task"] = task
 
 
-# ONE split-K reduction launch per backward pass (round 5): inside a backward pass a weight-gradient node whose output is a gradient-bucket
-# slot (gradsink: persistent storage that autograd adopts as ``param.grad`` by reference) runs only the split-K GEMM, leaves its partials in
-# a workspace that persists per layer, and the reduction of ALL such layers is one launch in an autograd end-of-pass callback
-# (``dir_conv_wgrad_reduce_batched``: same order per element, bit-identical): 52 launches of 5-8 us per ResNet-50 step become one, and
-# ``.grad`` is complete when ``backward()`` returns, as before. Not taken — the per-layer reduction runs at once — outside a backward pass, for
+# ONE split-K reduction launch per backward pass (round 5; OPT-IN: ``set_wgrad_batched_reduce(True)``): inside a backward pass a weight-gradient
+# node whose output is a gradient-bucket slot (gradsink: persistent storage that autograd adopts as ``param.grad`` by reference) runs only the
+# split-K GEMM, leaves its partials in a workspace that persists per layer, and the reduction of ALL such layers is one launch in an autograd
+# end-of-pass callback (``dir_conv_wgrad_reduce_batched``: same order per element, bit-identical): 52 launches of 5-8 us per ResNet-50 step
+# become one, and ``.grad`` is complete when ``backward()`` returns, as before. Measured NEUTRAL on the device-bound one-GPU loop (same-box A/B,
+# 18.435 vs 18.408 ms per train step, profiles/r05_ab_in_process.txt: the small launches already hid in the tails of their neighbours, the
+# one large reduction does not), so it is off by default — it removes 51 launches and 52 allocations per step from the HOST side, which is
+# what matters when several ranks share a box's cores. Never taken — the per-layer reduction runs at once — outside a backward pass, for
 # ordinary (not bucket) outputs (autograd may add them into a held gradient immediately), on the side stream, and when the data-parallel
-# engine's collectives are live (their hooks fire per parameter, before the end of the pass): ``set_wgrad_batched_reduce(False)``.
-_WGRAD_BATCH = {"on": True, "pending": {}, "task": None, "ws": {}, "tables": {}}
+# engine's collectives are live (their hooks fire per parameter, before the end of the pass).
+_WGRAD_BATCH = {"on": False, "pending": {}, "task": None, "ws": {}, "tables": {}}
 
 
 def set_wgrad_batched_reduce(enabled):
