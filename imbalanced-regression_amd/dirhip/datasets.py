@@ -234,6 +234,7 @@ class DeviceImageCache:
         self.labels = torch.zeros((self.n, 1), dtype=torch.float32, device=self.device)
         self.weights = torch.ones((self.n, 1), dtype=torch.float32, device=self.device)
         self.have = np.zeros(self.n, dtype=bool)                     # host side: which samples have been stored
+        self._stored = None                                          # event behind the latest put (puts run on the prefetcher's side stream)
 
     def put(self, index, u8, labels, weights):
         """``index``: host int64 ``[b]``; ``u8``: device ``[b, S, S, 3]`` (resized, not augmented); labels / weights: device ``[b, 1]``."""
@@ -242,6 +243,9 @@ class DeviceImageCache:
         self.u8.index_copy_(0, idx_d, u8)
         self.labels.index_copy_(0, idx_d, labels.reshape(-1, 1).float())
         self.weights.index_copy_(0, idx_d, weights.reshape(-1, 1).float())
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._stored = ev
         self.have[idx_h.numpy()] = True
 
     def covers(self, index):
@@ -251,6 +255,8 @@ class DeviceImageCache:
         """One pass over the samples ``index`` (a shard of the epoch), ``batch_size`` at a time, in a fresh random order: yields what the
         loader path yields — ``(network input, labels, weights[, valid])`` on the device."""
         index = torch.as_tensor(index, dtype=torch.int64)
+        if self._stored is not None:                                 # a pass may start while the last stores are still queued on another stream
+            torch.cuda.current_stream(self.device).wait_event(self._stored)
         order = torch.randperm(len(index), generator=generator) if shuffle else torch.arange(len(index))
         valid_t = None if valid is None else torch.as_tensor(valid, dtype=torch.bool)
         for s0 in range(0, len(index), batch_size):
