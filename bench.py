@@ -681,6 +681,23 @@ def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s,
     return res
 
 
+def library_baseline(batch, timeout_s=240):
+    """A second measured baseline: the reference's ResNet-50 as plain torch modules on the vendor library (MIOpen) under
+    torch.autocast(bfloat16), same GPU, same batch — tools/library_resnet.py in a CHILD process (MIOpen's kernel search takes ~70 s on a fresh
+    box; nothing of it is loaded into this process, whose training steps are asserted library-free by the tests)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "library_resnet.py"), str(batch), "bf16"]
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    steps = [float(l.split(":")[-1].split("ms")[0]) for l in p.stdout.splitlines() if l.startswith("amp=torch.bfloat16") and " step " in l]
+    if p.returncode != 0 or len(steps) < 3:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    ms = min(steps[1:])
+    return {"what": "imdb-wiki-dir/resnet.py as plain torch modules on the vendor library (MIOpen conv / BatchNorm), torch.autocast(bfloat16), torch.optim.Adam, "
+                    "channels_last, L1 loss on the prediction; no FDS, no epoch-tail forward; child process",
+            "batch": batch, "ms_per_train_step": ms, "images_per_sec": batch / ms * 1e3, "first_step_s": steps[0] / 1e3, "wall_s": time.perf_counter() - t0}
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The reference's training loop on the host cores, next to the GPU number (a reported baseline, not the target):
       * the loop of BASELINE configs[1] at the CPU-runnable batch of configs[0]: ResNet-50 + FDS + LDS weights + l1 + Adam, B=8, an
@@ -907,6 +924,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo), to run the N > 1 "
                     "control flow on a one-GPU box; the throughput it prints is meaningless")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-library-baseline", action="store_true", help="skip the vendor-library (MIOpen, torch.autocast) train step of the same network in a child process (~80 s)")
     ap.add_argument("--no-input-pipeline", action="store_true", help="skip the real-file input pipeline probe (synthetic JPEGs through the DataLoader)")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--no-float32-mode", action="store_true", help="skip the float32 (parity-exact) mode leg")
@@ -1135,6 +1153,17 @@ def main():
             log("input pipeline probe done")
         except Exception as e:                                          # noqa: BLE001  (a measurement, never a reason to lose the bench line)
             result["input_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+    if full and not args.no_library_baseline:
+        try:
+            torch.cuda.empty_cache()
+            lb = library_baseline(args.batch)
+            if "ms_per_train_step" in lb:
+                lb["this_build_train_step_ms"] = dt_train / args.steps * 1e3
+                lb["speedup_of_the_train_step"] = lb["ms_per_train_step"] / lb["this_build_train_step_ms"]
+            result["library_baseline"] = lb
+            log("library baseline done")
+        except Exception as e:                                          # noqa: BLE001  (a measurement, never a reason to lose the bench line)
+            result["library_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         log("cpu baseline done")

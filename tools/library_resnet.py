@@ -89,7 +89,8 @@ if __name__ == "__main__":
     import time
     dev = torch.device("cuda", 0)
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    for amp in (torch.bfloat16, None):
+    which = sys.argv[2] if len(sys.argv) > 2 else "both"              # bf16 | f32 | both
+    for amp in [a for a, tag in ((torch.bfloat16, "bf16"), (None, "f32")) if which in (tag, "both")]:
         m = AutocastModel(LibraryResNet50().to(dev).to(memory_format=torch.channels_last), amp)
         m.train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
