@@ -226,6 +226,8 @@ class DeviceImageCache:
     augmentation on the GPU (``DeviceAugment``): the same distribution of network inputs as the reference's loader, no decode after epoch 0."""
 
     def __init__(self, n, img_size, device, max_bytes=128 << 30):
+        # (a CONTAINER: it computes nothing — the augmentation it hands its batches to is the GPU kernel; a host device only serves the CPU tests
+        #  of its index / order / coverage logic)
         self.n, self.s, self.device = int(n), int(img_size), torch.device(device)
         nbytes = self.n * self.s * self.s * 3
         if nbytes > max_bytes:
@@ -243,9 +245,10 @@ class DeviceImageCache:
         self.u8.index_copy_(0, idx_d, u8)
         self.labels.index_copy_(0, idx_d, labels.reshape(-1, 1).float())
         self.weights.index_copy_(0, idx_d, weights.reshape(-1, 1).float())
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._stored = ev
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._stored = ev
         self.have[idx_h.numpy()] = True
 
     def covers(self, index):

@@ -71,3 +71,46 @@ def test_device_resize_refuses_cpu_target():
     assert lib.dir_resize_u8_workspace(256, 224, 5, 1000) > 256 * 2 * 224 * 7 * 4 and lib.dir_resize_u8_workspace(0, 224, 5, 0) == 0
     assert lib.dir_resize_u8(None, None, None, 1, 224, 10, 3, None, 0, None) == -1
     assert lib.dir_sgd_step(None, 1, 0.1, 0.9, 0.0, 0.0, 0, 0, None) == -1
+
+
+def test_device_image_cache_index_order_and_coverage_logic():
+    """datasets.DeviceImageCache (round 5) as a container, on the host: coverage only once every requested sample was stored, one pass = every
+    sample of the shard exactly once in a fresh order, labels / weights / the padded-row flag travel with their images, the last batch is ragged."""
+    import numpy as np
+    import torch
+    from dirhip.datasets import DeviceImageCache
+    n, s = 23, 4
+    imgs = torch.arange(n * s * s * 3, dtype=torch.int64).remainder(251).to(torch.uint8).view(n, s, s, 3)
+    labels = torch.arange(n, dtype=torch.float32).view(-1, 1)
+    weights = labels * 0.5 + 1
+    c = DeviceImageCache(n, s, "cpu")
+    first = torch.tensor([4, 0, 22, 9])
+    assert not c.covers(first)
+    c.put(first, imgs[first], labels[first], weights[first])
+    assert c.covers(first) and c.covers([0, 22]) and not c.covers(range(n))
+    rest = torch.tensor([i for i in range(n) if i not in set(first.tolist())])
+    c.put(rest, imgs[rest], labels[rest], weights[rest])
+    assert c.covers(range(n))
+    shard = torch.tensor([3, 3, 7, 11, 0, 22, 5, 6, 1, 2, 9])             # (a padded shard repeats samples)
+    valid = [True] * 9 + [False, False]
+    seen, nb = [], 0
+    for x, y, w, v in c.batches(shard, 4, lambda u8: u8.clone(), valid=valid, generator=torch.Generator().manual_seed(0)):
+        ids = y.view(-1).long()
+        assert torch.equal(x, imgs[ids]) and torch.equal(w, weights[ids]) and v.dtype == torch.bool and len(v) == len(ids) <= 4
+        seen += list(zip(ids.tolist(), v.tolist()))
+        nb += 1
+    assert nb == 3 and sorted(i for i, _ in seen) == sorted(shard.tolist()) and sum(1 for _, ok in seen if not ok) == 2
+    order_a = [i for i, _ in seen]
+    order_b = [int(i) for b_ in c.batches(shard, 4, lambda u8: u8, valid=valid, generator=torch.Generator().manual_seed(1)) for i in b_[1].view(-1)]
+    assert order_a != order_b                                                # a fresh order per pass
+    with np.testing.assert_raises(ValueError):
+        DeviceImageCache(10 ** 6, 224, "cpu", max_bytes=1 << 30)             # the budget is checked before anything is allocated
+
+
+def test_shard_subset_carries_the_dataset_index_for_the_cache():
+    sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
+    from dirhip.train_main import _ShardSubset
+    base = [("img%d" % i, float(i), 1.0) for i in range(10)]
+    sub = _ShardSubset(base, [7, 2, 2], [True, True, False], with_index=True)
+    assert len(sub) == 3 and sub[0] == ("img7", 7.0, 1.0, True, 7) and sub[2] == ("img2", 2.0, 1.0, False, 2)
+    assert _ShardSubset(base, [7], [True])[0] == ("img7", 7.0, 1.0, True)
