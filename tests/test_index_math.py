@@ -11,7 +11,9 @@ convolutions in float64. They pin the formulas (not the kernels — those are co
     half-swap swizzle on the SOURCE side, the transposing-read lane mapping (as pinned on the GPU by dir_probe_tr16), the per-lane
     patch slot of a pixel, taps as row offsets, operand k order and the C/D layout — an emulated workgroup reproduces dW;
   * the patch-staged 3x3 kernel's addressing (csrc/dir_conv.hip, conv3x3_patch_kernel): the tap row is an immediate under the
-    XOR swizzle because the row pitch is a multiple of 16 rows; fragment address = base ^ (kk << 5).
+    XOR swizzle because the row pitch is a multiple of 16 rows; fragment address = base ^ (kk << 5);
+  * the split-K reductions of the weight gradients (csrc/dir_conv_wgrad.hip): the per-layer kernel and the one-launch-for-all-layers kernel
+    (round 5) visit every element exactly once and add its partials in the SAME order — emulated in float32, bit-equal.
 """
 import numpy as np
 import pytest
@@ -305,3 +307,51 @@ def test_patch_kernel_tap_rows_are_immediates_under_the_swizzle(wi, P):
             base = row * 128 + ((fhalf ^ z) << 4)
             for kk in range(4):
                 assert row * 128 + (((kk * 2 + fhalf) ^ z) << 4) == base ^ (kk << 5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layers", [[(64 * 64, 7), (512 * 9 * 512 // 64, 16)], [(4096, 1), (64 * 3 * 64, 33), (2048 * 64, 2)]])
+def test_batched_splitk_reduction_adds_in_the_per_layer_kernels_order(layers):
+    """conv_wgrad_reduce_kernel: block = 16 float4 columns x 16 split lanes; lane sl adds splits sl, sl + 16, ... in order, the lanes are then
+    added in lane order. conv_wgrad_reduce_batched_kernel walks the same column groups with a grid-stride loop (gridDim.x = 512), one
+    blockIdx.y per layer. Emulated here in float32: every element once, identical sums."""
+    RD_COLS, RD_LANES, GRID_X = 16, 16, 512
+    rng = np.random.default_rng(0)
+
+    def column(part, splits, i):                                          # one float4 element's sum, as both kernels form it
+        lanes = []
+        for sl in range(RD_LANES):
+            s = np.float32(0.0)
+            for k in range(sl, splits, RD_LANES):
+                s = np.float32(s + part[k, i])
+            lanes.append(s)
+        t = lanes[0]
+        for k in range(1, RD_LANES):
+            t = np.float32(t + lanes[k])
+        return t
+    for n, splits in layers:
+        assert n % 4 == 0
+        part = rng.normal(0, 1, (splits, n)).astype(np.float32)
+        # per-layer kernel: grid = ceil(n / 4 / 16) blocks, block b owns float4 columns 16 b .. 16 b + 15
+        visited_single = np.zeros(n // 4, np.int32)
+        for b in range((n // 4 + RD_COLS - 1) // RD_COLS):
+            for col in range(RD_COLS):
+                i4 = b * RD_COLS + col
+                if i4 * 4 < n:
+                    visited_single[i4] += 1
+        # batched kernel: the same groups, strided over GRID_X blocks
+        visited_batched = np.zeros(n // 4, np.int32)
+        groups = (n // 4 + RD_COLS - 1) // RD_COLS
+        for bx in range(min(GRID_X, groups + 3)):
+            gi = bx
+            while gi < groups:
+                for col in range(RD_COLS):
+                    i4 = gi * RD_COLS + col
+                    if i4 * 4 < n:
+                        visited_batched[i4] += 1
+                gi += GRID_X
+        assert np.all(visited_single == 1) and np.all(visited_batched == 1)
+        # the order of additions per element does not depend on which kernel visits it: spot-check the arithmetic against a float64 sum
+        for i in rng.integers(0, n, 8):
+            v = column(part, splits, int(i))
+            assert abs(float(v) - float(part[:, i].astype(np.float64).sum())) <= 1e-5 * max(1.0, float(np.abs(part[:, i]).sum()))
