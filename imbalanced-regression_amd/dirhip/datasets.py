@@ -80,11 +80,12 @@ def ragged_collate(samples):
 
 
 class PinnedStager:
-    """Host-to-device copies of large PAGEABLE batches through a small ring of pinned buffers: the runtime's own pageable copy is synchronous
-    and serialises with the kernel launches of every other thread (measured: the training thread enqueues a step in 37 ms instead of 14 ms
-    while such copies run); a host memcpy into pinned memory (GIL released) followed by an asynchronous DMA does not. A buffer is reused
-    once the copy out of it has finished (event). The loader's own ``pin_memory`` would allocate a new pinned block per (differently sized)
-    ragged batch — tens of seconds for the pool and a fragmented host allocator."""
+    """OPTIONAL, off everywhere by default: host-to-device copies of large PAGEABLE batches through a small ring of pinned buffers (a host
+    memcpy into pinned memory, GIL released, then an asynchronous DMA; a buffer is reused once the copy out of it has finished). Built to test
+    whether the runtime's synchronous pageable copy was what held the file-fed loop back — it was not: 5.6-5.8 k img/s with the ring against
+    6.4 k without (profiles/r05_input_pipeline_end_to_end.txt; the bound is the loaders' hand-over of the ragged batches). Kept as the
+    measurement knob of ``DeviceResize(stager=)`` / ``tools/probe_input_pipeline.py e2e``. (The loader's own ``pin_memory`` would allocate a new
+    pinned block per differently sized ragged batch: tens of seconds for the pool and a fragmented host allocator.)"""
 
     def __init__(self, nbuf=3):
         self.bufs, self.events, self.i = [None] * nbuf, [None] * nbuf, 0

@@ -336,7 +336,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
         aug_dtype = torch.bfloat16 if args.amp == 'bf16' else torch.float32
         aug_train = datasets.DeviceAugment(args.img_size, train=True, dtype=aug_dtype) if raw else None
         aug_eval = datasets.DeviceAugment(args.img_size, train=False, dtype=aug_dtype) if raw else None
-        dev_resize = datasets.DeviceResize(args.img_size, device, stager=datasets.PinnedStager()) if args.gpu_resize else None
+        dev_resize = datasets.DeviceResize(args.img_size, device) if args.gpu_resize else None     # (PinnedStager measured slower: off, as in bench.py)
         collate = datasets.ragged_collate if args.gpu_resize else None
 
         # --gpu_resize hands over RAGGED file-size batches (~4x the bytes, a different size every time): pageable, like the configuration
