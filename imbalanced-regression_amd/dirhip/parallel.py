@@ -251,6 +251,9 @@ class DataParallelEngine(nn.Module):
         self._callback_queued = False
         self._decided = False               # every backward pass decides for itself (forward, forward, backward, backward: the second
                                             # pass finds the first one's averaged gradients held and must take the accumulation form)
+        for b in self._buckets:             # ... and counts its own gradients: a second backward pass without a forward in between
+            b.pending = len(b.params)       # (which is what re-arms the buckets otherwise) would never launch its collectives
+            b.work = None
 
     def comm_report(self):
         """Observability of the N > 1 path (bench.py): ranks, bucket sizes, and — when ``measure_comm`` was on — the time the compute

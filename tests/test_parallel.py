@@ -112,3 +112,45 @@ def test_gradient_accumulation_world_size_2_gloo(tmp_path):
     for k, p in net.named_parameters():
         assert torch.equal(g0[k], g1[k]), k
         assert torch.allclose(g0[k], p.grad, rtol=1e-5, atol=1e-6), k
+
+
+def _ffbb_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dirhip import conv as C
+    from dirhip.parallel import DataParallelEngine
+    C.set_wgrad_batched_reduce(True)
+    eng = DataParallelEngine(_net(), bucket_mb=0.001)
+    # live collectives start from per-parameter hooks, before the end of the backward pass: the one-launch-per-pass weight-gradient
+    # reduction (conv.set_wgrad_batched_reduce) must be off under them
+    assert C._WGRAD_BATCH["on"] is False
+    eng.train()
+    d = np.load(os.path.join(tmp, "data.npz"))
+    x, y = torch.tensor(d["x"]), torch.tensor(d["y"])
+    losses = [((eng(x[it, rank::world]) - y[it, rank::world]) ** 2).mean() for it in range(2)]       # forward, forward ...
+    for l in losses:                                                                                  # ... backward, backward
+        l.backward()
+    # the first pass is a plain one (pre-scaled output gradient), the second finds the averaged gradients held and takes the accumulation form
+    assert eng.stats["bucket_scale_kernels"] == len(eng._buckets)
+    torch.save({k: p.grad.clone() for k, p in eng.module.named_parameters()}, os.path.join(tmp, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_forwards_then_two_backwards_world_size_2_gloo(tmp_path):
+    """the accumulation decision is taken per BACKWARD pass (reset when a pass finishes), so forward, forward, backward, backward
+    ends with the sum of the two rank-averaged gradients — not world * mean_1 + mean_2."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 1, (2, 8, 3, 6, 6)).astype(np.float32)
+    y = rng.normal(0, 1, (2, 8, 1)).astype(np.float32)
+    np.savez(tmp_path / "data.npz", x=x, y=y)
+    port = 35000 + int(rng.integers(0, 2000))
+    mp.spawn(_ffbb_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    net = _net()
+    for it in range(2):
+        ((net(torch.tensor(x[it])) - torch.tensor(y[it])) ** 2).mean().backward()
+    for k, p in net.named_parameters():
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.allclose(g0[k], p.grad, rtol=1e-5, atol=1e-6), k
