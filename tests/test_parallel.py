@@ -154,3 +154,56 @@ def test_two_forwards_then_two_backwards_world_size_2_gloo(tmp_path):
     for k, p in net.named_parameters():
         assert torch.equal(g0[k], g1[k]), k
         assert torch.allclose(g0[k], p.grad, rtol=1e-5, atol=1e-6), k
+
+
+class _NetWithUnused(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.body = _net_raw()
+        self.unused = nn.Linear(4, 4)                                 # never part of the graph: its gradients must arrive as zeros
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _edge_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dirhip.parallel import DataParallelEngine
+    eng = DataParallelEngine(_NetWithUnused(), bucket_mb=0.001)
+    eng.train()
+    opt = torch.optim.SGD(eng.parameters(), lr=0.05)
+    d = np.load(os.path.join(tmp, "data.npz"))
+    x, y = torch.tensor(d["x"]), torch.tensor(d["y"])
+    for it in range(3):
+        loss = ((eng(x[it, rank::world]) - y[it, rank::world]) ** 2).mean()
+        opt.zero_grad(set_to_none=False)                              # gradients stay allocated (zero-valued): classed as accumulating, same result
+        loss.backward()
+        opt.step()
+    un = eng.module.unused
+    assert un.weight.grad is not None and float(un.weight.grad.abs().sum()) == 0.0 and float(un.bias.grad.abs().sum()) == 0.0
+    torch.save({k: v.clone() for k, v in eng.module.state_dict().items()}, os.path.join(tmp, f"w{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_unused_parameters_and_kept_zero_gradients_world_size_2_gloo(tmp_path):
+    """Parameters outside the graph get zero gradients in their bucket (every bucket's collective still runs on every rank: no hang), and a
+    loop that keeps its gradients allocated (zero_grad(set_to_none=False)) ends where the set-to-none loop and the single process end."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(4)
+    x = rng.normal(0, 1, (3, 8, 3, 6, 6)).astype(np.float32)
+    y = rng.normal(0, 1, (3, 8, 1)).astype(np.float32)
+    np.savez(tmp_path / "data.npz", x=x, y=y)
+    port = 37000 + int(rng.integers(0, 2000))
+    mp.spawn(_edge_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    net = _NetWithUnused()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    for it in range(3):
+        loss = ((net(torch.tensor(x[it])) - torch.tensor(y[it])) ** 2).mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+    for k, a in net.state_dict().items():
+        assert torch.equal(w0[k], w1[k]), f"ranks diverged on {k}"
+        assert torch.allclose(w0[k], a, rtol=1e-5, atol=1e-6), k
