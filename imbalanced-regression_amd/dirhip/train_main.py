@@ -353,7 +353,10 @@ def run(argv=None, dataset_default='imdb_wiki'):
             print(f"Training images cached in HBM once decoded: {cache.u8.numel() / 2 ** 30:.2f} GiB")
 
         def train_batches(epoch):
-            idx, valid = shard_indices(n_train, rank, world, epoch_seed=epoch, with_valid=True)
+            # (with the HBM cache under data parallelism the partition of the training set over the ranks is FIXED — every rank then finds its
+            #  whole shard cached from the second pass on; the order inside the shard is still drawn anew for every pass. Without the cache the
+            #  partition is redrawn every epoch, like a DistributedSampler's)
+            idx, valid = shard_indices(n_train, rank, world, epoch_seed=0 if (cache is not None and world > 1) else epoch, with_valid=True)
 
             def batches():
                 # (decided at the START of every pass: the feature pass of an epoch already finds what its training pass stored)
