@@ -194,6 +194,7 @@ def _wgrad_side_done(device, side, *operands):
 # ordinary (not bucket) outputs (autograd may add them into a held gradient immediately), on the side stream, and when the data-parallel
 # engine's collectives are live (their hooks fire per parameter, before the end of the pass).
 _WGRAD_BATCH = {"on": False, "pending": {}, "task": None, "ws": {}, "tables": {}}
+_COLLECTIVES_LIVE = [0]          # engines whose per-parameter collectives are live (parallel.DataParallelEngine): no batching while > 0
 
 
 def set_wgrad_batched_reduce(enabled):
@@ -219,16 +220,27 @@ def wgrad_flush():
             st["tables"][idx] = tab
         rows.clear()
         L.check(L.lib().dir_conv_wgrad_reduce_batched(L.ptr(tab[1]), len(key), L.stream_ptr(torch.device("cuda", idx))), "dir_conv_wgrad_reduce_batched")
+        # the reduction wrote the bucket slots: correct only if AccumulateGrad ADOPTED each slot as ``param.grad`` (it clones instead when
+        # something else holds the view): a clone taken before this launch holds unreduced memory — fail loudly, never train on it
+        for row in key:
+            p = gradsink.owner_of_slot(row[3])
+            if p is None or p.grad is None or p.grad.data_ptr() != row[3]:
+                raise RuntimeError("batched weight-gradient reduction: autograd did not adopt the gradient-bucket slot as .grad for a layer "
+                                   "(the gradient it holds was copied before the end-of-pass reduction and is invalid); "
+                                   "turn conv.set_wgrad_batched_reduce off for this graph")
 
 
 def _wgrad_batch_slot(dw, from_sink, nbytes):
     """The persistent workspace for this layer when its reduction can wait for the end of the backward pass, else None."""
     st = _WGRAD_BATCH
-    if not (st["on"] and from_sink and dw.is_cuda and not _WGRAD_SIDE["on"]):
+    if not (st["on"] and from_sink and dw.is_cuda and not _WGRAD_SIDE["on"]) or _COLLECTIVES_LIVE[0] > 0:
         return None
     task = torch._C._current_graph_task_id()
-    if task == -1:
+    if task == -1 or torch.is_grad_enabled():                    # (grad mode on INSIDE a backward pass = create_graph: AccumulateGrad clones)
         return None
+    owner = gradsink.owner_of_slot(dw.data_ptr())
+    if owner is None or owner._backward_hooks or getattr(owner, "_post_accumulate_grad_hooks", None):
+        return None                                               # hooks see (or replace) the gradient before the end of the pass
     idx = dw.device.index if dw.device.index is not None else torch.cuda.current_device()
     rows = st["pending"].setdefault(idx, [])
     if any(r[3] == dw.data_ptr() for r in rows):                 # the same gradient twice in one pass (shared weights): not batched

@@ -6,18 +6,32 @@ dgamma / dbeta, the tail's linear layer) allocate their outputs through ``out_fo
 bucket. Every call hands out a FRESH view object, so autograd's AccumulateGrad takes it over as ``param.grad`` without a copy.
 Single process (no engine buckets): ``out_for`` is ``torch.empty``.
 """
+import weakref
+
 import torch
 
 _SINKS = {}                       # parameter storage address -> zero-argument callable returning a fresh view of its bucket slot
+_SLOT_OWNER = {}                  # bucket-slot address -> weak reference to the parameter whose gradient lives there
 
 
-def register(param, factory):
+def register(param, factory, slot_ptr=None):
     _SINKS[param.data_ptr()] = factory
+    if slot_ptr is not None:
+        _SLOT_OWNER[int(slot_ptr)] = weakref.ref(param)
 
 
 def unregister(params):
     for p in params:
         _SINKS.pop(p.data_ptr(), None)
+    dead = [k for k, r in _SLOT_OWNER.items() if r() is None or any(r() is p for p in params)]
+    for k in dead:
+        _SLOT_OWNER.pop(k, None)
+
+
+def owner_of_slot(slot_ptr):
+    """The parameter whose gradient-bucket slot starts at ``slot_ptr`` (None: not a registered slot, or the parameter is gone)."""
+    r = _SLOT_OWNER.get(slot_ptr)
+    return r() if r is not None else None
 
 
 def lookup(param):

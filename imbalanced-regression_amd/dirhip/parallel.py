@@ -78,6 +78,16 @@ class _Bucket:
         return seg.as_strided(p.shape, p.stride()) if self.dense[pi] else seg.view_as(p)
 
 
+def _conv_batching():
+    from . import conv as _conv
+    return _conv._WGRAD_BATCH["on"] and _conv._COLLECTIVES_LIVE[0] == 0
+
+
+def _release_collectives_guard():
+    from . import conv as _conv
+    _conv._COLLECTIVES_LIVE[0] = max(0, _conv._COLLECTIVES_LIVE[0] - 1)
+
+
 class DataParallelEngine(nn.Module):
     """Wrap ``module`` for one-process-per-GPU training. Plain ``loss.backward()`` + ``optimizer.step()`` work:
     the gradient exchange is driven by autograd hooks and completes before ``backward()`` returns."""
@@ -97,6 +107,9 @@ class DataParallelEngine(nn.Module):
             # complete when its node returns — the one-launch-per-pass split-K reduction of conv.py is for the one-process loop
             from . import conv as _conv
             _conv.set_wgrad_batched_reduce(False)
+            _conv._COLLECTIVES_LIVE[0] += 1                 # guards the point of use too: turning the switch back on later changes nothing
+            import weakref
+            weakref.finalize(self, _release_collectives_guard)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.amp_dtype = amp_dtype
         self.channels_last = channels_last
@@ -189,7 +202,7 @@ class DataParallelEngine(nn.Module):
                     # the gradient kernels write into the bucket — unless the parameter still HOLDS a gradient (accumulation over
                     # several backward passes, zero_grad(set_to_none=False)): the slot is that gradient, so the kernel gets a new tensor
                     # and autograd accumulates as usual
-                    gradsink.register(p, lambda b=b, pi=pi, p=p: b.fresh_view(pi) if p.grad is None else None)
+                    gradsink.register(p, lambda b=b, pi=pi, p=p: b.fresh_view(pi) if p.grad is None else None, slot_ptr=b.views[pi].data_ptr())
             self._signature = sig
         for b in self._buckets:
             b.pending = len(b.params)
@@ -199,6 +212,7 @@ class DataParallelEngine(nn.Module):
         self._decided = False
 
     def _on_grad_ready(self, p):
+        assert not _conv_batching(), "live collectives with the batched weight-gradient reduction on: the bucket would be reduced over ranks before its split-K sum"
         if not self._callback_queued:
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
             self._callback_queued = True

@@ -125,6 +125,9 @@ def _ffbb_worker(rank, world, port, tmp):
     # live collectives start from per-parameter hooks, before the end of the backward pass: the one-launch-per-pass weight-gradient
     # reduction (conv.set_wgrad_batched_reduce) must be off under them
     assert C._WGRAD_BATCH["on"] is False
+    # ... and stays ineffective if somebody turns it back on while the engine lives (guarded at the point of use)
+    C.set_wgrad_batched_reduce(True)
+    assert C._COLLECTIVES_LIVE[0] > 0 and C._wgrad_batch_slot(torch.empty(4), True, 16) is None
     eng.train()
     d = np.load(os.path.join(tmp, "data.npz"))
     x, y = torch.tensor(d["x"]), torch.tensor(d["y"])

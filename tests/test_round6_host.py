@@ -1,0 +1,57 @@
+"""Round-6 host tests (no GPU): the bench line's size contract."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _fat_result():
+    blob = "x" * 400
+    fl = {"nominal": {"total_ms": 9.03, "conv_fwd_dgrad_wgrad_ms": 4.5}, "measured_on_this_box": {"total_ms": 12.0}}
+    rows = [{"kernel": f"kernel {i} " + blob[:60], "bound": "hbm", "shape": "N=191509 C=2048 Nb=100", "ms": 0.29712345678, "algorithmic_bytes": 1.57e9,
+             "achieved": 5281.123456789, "peak": 8000.0, "unit": "GB/s", "frac": 0.66123456789, "frac_of_measured_peak": 0.9, "note": blob} for i in range(20)]
+    return {"metric": "images/sec ResNet-50+FDS IMDB-WIKI 224x224 (train loop incl. FDS epoch tail)", "value": 10233.123456789, "unit": "images/sec", "n_gpus": 1,
+            "steps": 20, "warmup": 5, "ms_per_step": 25.0123456789, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic", "config": {"workload": blob, "per_gpu_batch": 256, "global_batch": 256, "parallelism": "dp1", "final_loss": 7.123456789},
+            "train_only_images_per_sec": 13589.123456789,
+            "roofline": {"bound": "mfma", "kernel": blob[:150], "achieved": 492.1026226247471, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.19684104904989883,
+                         "traffic": 208146326.20408162, "algorithmic_bytes_per_launch": 202819542.2, "traffic_detail": {"source": blob, "a": 1.0}, "method": blob,
+                         "launches_per_step": 113.0, "avg_launch_us": 73.09, "ms_per_step_in_this_kernel": 8.259214750000012, "mfma_busy": 0.288},
+            "roofline_step": {"achieved_ms": 18.84, "floor": fl, "frac_of_nominal_floor": 0.48, "frac_of_measured_peak_floor": 0.64, "note": blob},
+            "kernel_rooflines": rows, "conv_layers": {"rows": [[1, 2, 3, 4, 5, 6, "fwd", 1.0, 2.0, 1]] * 200}, "peaks": {"a": 1.0}, "input_pipeline": {"x": blob * 10},
+            "cpu_baseline": {"value": 8.13, "unit": "images/sec", "cores": 64, "kind": "port", "batch": 8, "sample": blob[:200], "micro": [{"what": blob}] * 8,
+                             "batch_note": blob},
+            "comm": {"rccl_ranks": 8, "backend": "nccl", "reduce_op": "AVG", "buckets": [{"MB": 32.0, "allreduce_ms": 0.5, "bus_GBs": 100.123456}] * 3,
+                     "allreduce_ms_per_step_if_serial": 1.5, "exposed_comm_ms_per_step": 0.2, "note": blob},
+            "detail": "gpurun_out/bench_detail.json"}
+
+
+def test_driver_line_is_short_and_keeps_the_contract_keys():
+    """the r05 line (20.5 KB) was not parsed by the driver. Whatever the legs return, the printed line stays under 8 KB, is valid
+    JSON on one line, and carries the contract's keys + roofline + cpu_baseline."""
+    import bench
+    line = bench.driver_line(_fat_result())
+    assert len(line) < 8192 and len(line) <= bench.MAX_LINE_BYTES, len(line)
+    assert "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    assert "conv_layers" not in d and "input_pipeline" not in d and "micro" not in d["cpu_baseline"]
+    assert len(d["kernel_rooflines"]) <= 7
+    assert d["value"] == 10233.0 or abs(d["value"] - 10233.123456789) < 1.0          # 5 significant digits
+
+
+def test_bench_extras_live_outside_bench_py():
+    """bench.py is the timed loop + the line; the minutes-long probes are tools/bench_extras.py."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ("def conv_layer_probe", "def input_pipeline_probe", "def library_baseline", "def float32_mode_probe"):
+        assert name not in src
+        assert name in open(os.path.join(ROOT, "tools", "bench_extras.py")).read()

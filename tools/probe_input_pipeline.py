@@ -1,4 +1,4 @@
-"""GPU probe of the real-file input pipeline (bench.py: input_pipeline).   python tools/probe_input_pipeline.py [e2e [gil switch interval] [depth] [pinned staging 0/1]]"""
+"""GPU probe of the real-file input pipeline (tools/bench_extras.py: input_pipeline).   python tools/probe_input_pipeline.py [e2e [gil switch interval] [depth] [pinned staging 0/1]]"""
 import json
 import os
 import sys
@@ -8,7 +8,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
-import bench  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_extras as bench  # noqa: E402
 
 if len(sys.argv) > 1 and sys.argv[1] == "e2e":
     kw = {}
