@@ -18,6 +18,7 @@
 //   wgrad   : M = Cout,    Ncol = R*S*Cin,  K = N*Ho*Wo    A = dy^T, B gathers x; split-K over blockIdx.z into float32
 //             partial tiles, summed in a fixed order by a second kernel (deterministic, no atomics)
 #include "dir_common.h"
+#include "dir_conv_shared.h"
 
 namespace {
 
@@ -208,6 +209,336 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_wgrad_reduce_kernel(const fl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile kernels (round 6). The gather kernels above run at a quarter of the float32 MFMA rate (4-byte gathers with an index decode per
+// element, one 32 x 32 tile per wavefront, one LDS stage): 160 ms per B = 256 training step, slower than the vendor library's float32
+// step. Same arithmetic — v_mfma_f32_32x32x2_f32 over k in the same order (k = (r, s, c), one K-step = 16 channels of one filter tap),
+// so forward and data gradient are BIT-IDENTICAL to the gather kernels — on a 128 x 128 (x 64, 64 x 128) workgroup tile, 64 x 64 per
+// wavefront, operands staged global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, out-of-image / out-of-range lanes
+// read beyond the buffer: the hardware writes zeros), two LDS stages, one barrier per K-step. A K-step is 16 KB of operands per 2048
+// MFMA cycles of a wavefront (8 B/clk/CU): the loop is bound by the matrix pipe, not by operand delivery like the bf16 kernels'.
+// An operand tile is staged in the order memory has it:
+//   K-contiguous (x / dy rows of forward and data gradient, forward weights [Cout][K]): rows of 64 B = 16 k, the four 16-B chunks of a
+//     row XOR-swizzled with (row >> 2) & 3 on the DMA's source side; a lane's fragment read is ONE ds_read_b128 per two MFMAs (its row,
+//     four consecutive k; the half-wave picks k = 2 j + (lane >> 5)): conflict-free for every 16-lane group of the instruction;
+//   k-major (data-gradient weights w[co][r][s][ci] read as B[k = (r, s, co)][n = ci], both weight-gradient operands dy[pixel][co],
+//     x[pixel + tap][ci]): 16 k-rows of T floats, fragment reads are 32 consecutive floats per half-wave (ds_read_b32).
+// Needs the K axis in whole 16-channel steps (Cin resp. Cout % 16 == 0) and 16-byte columns; the 7x7 stem (Cin = 3) and odd shapes
+// stay on the gather kernels.
+constexpr int FT_BK = 16, FT_ROWB = FT_BK * 4;
+constexpr int FT_OOB = (int)0x80000000;
+constexpr int FT_ABLATE = 0;            // measurement builds only (tools/ablate_f32.py patches this line): 1 = no DMA, 2 = no epilogue stores, 3 = no MFMA, 4 = no barriers / DMA waits
+enum { FT_FWD = 0, FT_DGRAD = 1, FT_WGRAD = 2 };
+
+struct ConvF32T {
+    ConvF32P c;
+    int ntn, nblocks;          // N tiles, workgroups per K split
+    int kbytes_a, kbytes_b;    // buffer extents in bytes
+    float inv_wo, inv_ho;      // reciprocals for the pixel decode of the weight gradient's K axis
+    int cls;                   // stride-2 data gradient by PARITY CLASS (blockIdx.y = 2 a + b): the rows of a tile are the pixels (2 i + a, 2 j + b) of
+                               // one class, c.M = pixels per class; only the filter taps r = (a + pad) mod 2, + 2, ... reach them, so the K loop
+                               // visits those taps only (the element-gather kernel multiplies the other 3/4 of its products by zero)
+};
+
+
+template <int TM, int TN, int MODE>
+__global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
+    const ConvF32P& p = q.c;
+    constexpr bool AKM = MODE == FT_WGRAD, BKM = MODE != FT_FWD;
+    constexpr int WGM = (TM == 128 && TN == 64) ? 4 : 2, WGN = 4 / WGM;
+    constexpr int WM = TM / WGM, WN = TN / WGN, MI = WM / 32, NI = WN / 32;
+    constexpr int NA = TM / 64, NB = TN / 64;                       // 1 KB DMA pieces per wavefront and K-step
+    constexpr int A_BYTES = TM * FT_ROWB, STAGE = (TM + TN) * FT_ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    int lin;
+    {
+        const int b = blockIdx.x, n8 = q.nblocks / 8, r8 = q.nblocks % 8, xcd = b % 8, i = b / 8;
+        lin = (xcd < r8 ? xcd * (n8 + 1) : r8 * (n8 + 1) + (xcd - r8) * n8) + i;
+    }
+    const int mt = lin / q.ntn, nt = lin - mt * q.ntn;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int cls_a = (MODE == FT_DGRAD && q.cls) ? (int)(blockIdx.y >> 1) : 0, cls_b = (MODE == FT_DGRAD && q.cls) ? (int)(blockIdx.y & 1) : 0;
+    const int kbeg = MODE == FT_WGRAD ? (int)blockIdx.y * p.klen : 0;
+    const int kend = MODE == FT_WGRAD ? ((kbeg + p.klen < p.K) ? kbeg + p.klen : p.K) : p.K;
+    // The LDS-DMA is inline assembly (cp_dma16) with an explicit s_waitcnt before each barrier: with the compiler-visible builtin and a
+    // run-time stage index the compiler drains the pending DMA (vmcnt(0)) in front of the first fragment read of every K-step — it cannot
+    // tell the two stages apart — which exposes the whole L2 round trip per step (measured: 100 instead of 125 TFLOP/s).
+    const cp_u32x4 rs_a = cp_rsrc(p.a, (uint32_t)q.kbytes_a);
+    const cp_u32x4 rs_b = cp_rsrc(p.b, (uint32_t)q.kbytes_b);
+    typedef __attribute__((address_space(3))) unsigned char* ft_lds_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(ft_lds_t)smem;
+
+    // ---- loader state. K-contiguous tiles: piece pa = rows 16 pa .. 16 pa + 15, lane -> row (lane >> 2), physical chunk lane & 3
+    // = logical chunk (lane & 3) ^ (lane >> 4). k-major tiles: piece = floats 256 pa .. of the [16][T] image, lane -> 4 consecutive columns.
+    const int rlc = ((lane & 3) ^ (lane >> 4)) * 4;                 // first k (float index inside the K-step) of this lane's chunk
+    int a_img[NA], a_y[NA], a_x[NA];                                // forward / data gradient: the pixel of the lane's A row (a_img < 0: no row)
+    int a_kr[NA], a_col[NA];                                        // weight gradient: k-row and column of the lane's chunk
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int pa = wave + 4 * i;
+        if (!AKM) {
+            const int m = m0 + 16 * pa + (lane >> 2);
+            const bool cl = MODE == FT_DGRAD && q.cls;
+            const int PH = MODE == FT_FWD ? p.Ho : (cl ? p.H >> 1 : p.H), PW = MODE == FT_FWD ? p.Wo : (cl ? p.W >> 1 : p.W);
+            a_img[i] = -1; a_y[i] = a_x[i] = 0;
+            if (m < p.M) {
+                a_x[i] = m % PW; const int qq = m / PW; a_y[i] = qq % PH; a_img[i] = qq / PH;
+                if (cl) { a_y[i] = 2 * a_y[i] + cls_a; a_x[i] = 2 * a_x[i] + cls_b; }
+            }
+            a_kr[i] = a_col[i] = 0;
+        } else {
+            const int f = 256 * pa + 4 * lane;
+            a_kr[i] = f / TM; a_col[i] = m0 + f % TM;
+            a_img[i] = a_y[i] = a_x[i] = 0;
+        }
+    }
+    int b_row[NB], b_kr[NB], b_col[NB], b_r[NB], b_s[NB], b_ci[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pb = wave + 4 * i;
+        b_row[i] = b_kr[i] = b_col[i] = b_r[i] = b_s[i] = b_ci[i] = 0;
+        if (!BKM) {
+            const int n = n0 + 16 * pb + (lane >> 2);
+            b_row[i] = n < p.Ncol ? n : -1;
+        } else {
+            const int f = 256 * pb + 4 * lane;
+            b_kr[i] = f / TN; b_col[i] = n0 + f % TN;
+            if (MODE == FT_WGRAD) {
+                const int nn = b_col[i] < p.Ncol ? b_col[i] : 0;
+                const int tap = nn / p.Cin;
+                b_ci[i] = nn - tap * p.Cin; b_r[i] = tap / p.S; b_s[i] = tap - b_r[i] * p.S;
+            }
+        }
+    }
+    const int CK = MODE == FT_FWD ? p.Cin : p.Cout;                 // channel extent of the K axis of forward / data gradient
+    // cursor of the next K-step to issue: channel offset and filter tap (parity-class data gradient: first tap and tap step per axis)
+    const int tstep = (MODE == FT_DGRAD && q.cls) ? 2 : 1;
+    const int r0 = (MODE == FT_DGRAD && q.cls) ? ((cls_a + p.pad) & 1) : 0, s0 = (MODE == FT_DGRAD && q.cls) ? ((cls_b + p.pad) & 1) : 0;
+    int ld_c = 0, ld_r = r0, ld_s = s0;
+    int nsteps;                                                     // K-steps of this workgroup
+    if (MODE == FT_WGRAD) nsteps = kbeg < kend ? (kend - kbeg + FT_BK - 1) / FT_BK : 0;
+    else nsteps = (r0 >= p.R || s0 >= p.S) ? 0 : ((p.R - r0 + tstep - 1) / tstep) * ((p.S - s0 + tstep - 1) / tstep) * (CK / FT_BK);
+
+    auto issue = [&](int stage, int k0) {
+        if (FT_ABLATE == 1) return;
+        const uint32_t sa = lds0 + (uint32_t)(stage * STAGE), sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pa = wave + 4 * i;
+            int off = FT_OOB;
+            if (MODE == FT_FWD) {
+                const int hi = a_y[i] * p.stride - p.pad + ld_r, wi = a_x[i] * p.stride - p.pad + ld_s;
+                if (a_img[i] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    off = ((((a_img[i] * p.H + hi) * p.W + wi) * p.Cin) + ld_c + rlc) * 4;
+            } else if (MODE == FT_DGRAD) {
+                const int th = a_y[i] + p.pad - ld_r, tw = a_x[i] + p.pad - ld_s;
+                if (a_img[i] >= 0 && th >= 0 && tw >= 0) {
+                    int ho, wo; bool ok;
+                    if (p.stride == 1) { ho = th; wo = tw; ok = true; }
+                    else if (p.stride == 2) { ho = th >> 1; wo = tw >> 1; ok = !((th | tw) & 1); }
+                    else { ho = th / p.stride; wo = tw / p.stride; ok = ho * p.stride == th && wo * p.stride == tw; }
+                    if (ok && ho < p.Ho && wo < p.Wo) off = ((((a_img[i] * p.Ho + ho) * p.Wo + wo) * p.Cout) + ld_c + rlc) * 4;
+                }
+            } else {
+                const int k = k0 + a_kr[i];
+                if (k < kend && a_col[i] < p.M) off = (k * p.Cout + a_col[i]) * 4;
+            }
+            cp_dma16(rs_a, sa + pa * 1024, off, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pb = wave + 4 * i;
+            int off = FT_OOB;
+            if (MODE == FT_FWD) {
+                if (b_row[i] >= 0) off = (b_row[i] * p.K + k0 + rlc) * 4;
+            } else if (MODE == FT_DGRAD) {
+                if (b_col[i] < p.Ncol) off = ((((ld_c + b_kr[i]) * p.R + ld_r) * p.S + ld_s) * p.Cin + b_col[i]) * 4;
+            } else {
+                const int k = k0 + b_kr[i];
+                if (k < kend && b_col[i] < p.Ncol) {
+                    int q1 = (int)((float)k * q.inv_wo), wo = k - q1 * p.Wo;
+                    if (wo < 0) { --q1; wo += p.Wo; } else if (wo >= p.Wo) { ++q1; wo -= p.Wo; }
+                    int img = (int)((float)q1 * q.inv_ho), ho = q1 - img * p.Ho;
+                    if (ho < 0) { --img; ho += p.Ho; } else if (ho >= p.Ho) { ++img; ho -= p.Ho; }
+                    const int hi = ho * p.stride - p.pad + b_r[i], wi = wo * p.stride - p.pad + b_s[i];
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) off = ((((img * p.H + hi) * p.W + wi) * p.Cin) + b_ci[i]) * 4;
+                }
+            }
+            cp_dma16(rs_b, sb + pb * 1024, off, 0);
+        }
+        if (MODE != FT_WGRAD) {                                    // next K-step: 16 more channels, then the next filter tap
+            ld_c += FT_BK;
+            if (ld_c == CK) { ld_c = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } }
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a stage)
+    uint32_t afo[MI], bfo[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * WM + mi * 32 + fi;
+        afo[mi] = AKM ? (uint32_t)(fh * TM * 4 + row * 4) : (uint32_t)(row * FT_ROWB);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * WN + ni * 32 + fi;
+        bfo[ni] = A_BYTES + (BKM ? (uint32_t)(fh * TN * 4 + row * 4) : (uint32_t)(row * FT_ROWB));
+    }
+    const uint32_t aswz = (uint32_t)((fi >> 2) & 3), bswz = aswz;    // (row >> 2) & 3 of a fragment row = (fi >> 2) & 3: tile rows start at multiples of 32
+
+    cf_f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+    // One K-step of MFMAs. The fragments of chunk c + 1 (four k) are requested BEFORE the eight MFMAs of chunk c are issued: a wavefront issues
+    // in order, so reads placed after its MFMAs would wait for all of them and then expose the LDS latency once per chunk (the compiler's own
+    // schedule of the straightforward loop; SQ counters: matrix pipe 59-67 % busy with 2-3 wavefronts per SIMD).
+    auto mfma_step = [&](int stage) {
+        const unsigned char* sbase = smem + stage * STAGE;
+        float4 ra[2][MI], rb[2][NI];
+        float ka[2][MI][2], kb[2][NI][2];
+        auto load = [&](int c, int buf) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                if (!AKM) ra[buf][mi] = *reinterpret_cast<const float4*>(sbase + afo[mi] + (((uint32_t)c ^ aswz) << 4));
+                else {
+                    ka[buf][mi][0] = *reinterpret_cast<const float*>(sbase + afo[mi] + (4 * c) * (TM * 4));
+                    ka[buf][mi][1] = *reinterpret_cast<const float*>(sbase + afo[mi] + (4 * c + 2) * (TM * 4));
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                if (!BKM) rb[buf][ni] = *reinterpret_cast<const float4*>(sbase + bfo[ni] + (((uint32_t)c ^ bswz) << 4));
+                else {
+                    kb[buf][ni][0] = *reinterpret_cast<const float*>(sbase + bfo[ni] + (4 * c) * (TN * 4));
+                    kb[buf][ni][1] = *reinterpret_cast<const float*>(sbase + bfo[ni] + (4 * c + 2) * (TN * 4));
+                }
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                               // four chunks of four k
+            const int cb = c & 1;
+            if (c < 3) load(c + 1, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks the reads below the MFMAs again)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {                        // MFMA j = 2 c + jj multiplies k = 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63)
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    a[mi] = AKM ? ka[cb][mi][jj] : (jj == 0 ? (fh ? ra[cb][mi].y : ra[cb][mi].x) : (fh ? ra[cb][mi].w : ra[cb][mi].z));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    b[ni] = BKM ? kb[cb][ni][jj] : (jj == 0 ? (fh ? rb[cb][ni].y : rb[cb][ni].x) : (fh ? rb[cb][ni].w : rb[cb][ni].z));
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        if (FT_ABLATE == 3) asm volatile("" :: "v"(a[mi]), "v"(b[ni]));
+                        else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+
+    int stage = 0;
+    if (nsteps > 0) {
+        issue(0, kbeg);
+        cp_dma_wait();
+        __syncthreads();
+        for (int it = 0; it < nsteps; ++it) {
+            if (it + 1 < nsteps) issue(stage ^ 1, kbeg + (it + 1) * FT_BK);    // next K-step in flight under this one's MFMAs
+            mfma_step(stage);
+            if (FT_ABLATE != 4) {
+                cp_dma_wait();                                      // this wavefront's pieces of the next stage have landed ...
+                __syncthreads();                                    // ... everyone's have, and everyone is done reading this stage
+            }
+            stage ^= 1;
+        }
+    }
+
+    // ---- store (C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
+    float* out = MODE == FT_WGRAD ? p.out + (size_t)blockIdx.y * p.M * p.Ncol : p.out;
+    if (FT_ABLATE == 2) {
+        float s_ = 0.0f;
+        for (int mi = 0; mi < MI; ++mi) for (int ni = 0; ni < NI; ++ni) for (int e = 0; e < 16; ++e) s_ += acc[mi][ni][e];
+        if (s_ == 1234.5f) out[t] = 1.0f;
+        return;
+    }
+    const bool fused = MODE == FT_DGRAD && (p.addend || p.addend2 || p.mask);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wn * WN + ni * 32 + fi;
+        if (col >= p.Ncol) continue;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int row = m0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row >= p.M) continue;
+                if (MODE == FT_DGRAD && q.cls) {                    // class row (img, i, j) -> pixel (2 i + a, 2 j + b)
+                    const int w2 = p.W >> 1, h2 = p.H >> 1, j = row % w2, qq = row / w2, i = qq % h2, img = qq / h2;
+                    row = (img * p.H + 2 * i + cls_a) * p.W + 2 * j + cls_b;
+                }
+                const size_t o = (size_t)row * p.Ncol + col;
+                float v = acc[mi][ni][e];
+                if (fused) {
+                    if (p.addend) v += p.addend[o];
+                    if (p.addend2) {
+                        const int w = row % p.W, qq = row / p.W, h = qq % p.H, n = qq / p.H;
+                        if (!((h | w) & 1)) v += p.addend2[(((size_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Ncol + col];
+                    }
+                    if (p.mask && !(p.mask[o] > 0.0f)) v = 0.0f;
+                }
+                out[o] = v;
+            }
+    }
+}
+
+// (A form of the forward kernel with a dedicated LOADER wavefront — wavefront 4 issues all DMA pieces, wavefronts 0-3 only MFMAs — was built,
+// bit-identical, and measured 3-40 % SLOWER on every ResNet-50 layer: profiles/r06_f32_loader_wave_negative.txt; code at the commit before this
+// one. The phase ablation that motivated it: profiles/r06_f32_tile_phase_ablation.txt — time ~ MFMA-only + 0.7 x DMA-only, unchanged without
+// barriers / DMA waits.)
+// Is the tile kernel applicable? (whole 16-channel K-steps, 16-byte columns, 32-bit byte offsets; the weight gradient's pixel decode is
+// exact below 2^24 pixels)
+bool ft_ok(int mode, const ConvF32P& p, size_t a_elems, size_t b_elems) {
+    if (a_elems * 4 >= (1ull << 31) || b_elems * 4 >= (1ull << 31)) return false;
+    if (mode == FT_FWD) return p.Cin % FT_BK == 0;
+    if (mode == FT_DGRAD) return p.Cout % FT_BK == 0 && p.Cin % 4 == 0;
+    return p.Cout % 4 == 0 && p.Cin % 4 == 0 && p.K < (1 << 24);
+}
+
+// split-K of the weight gradient on TM x TN tiles: ~1024 workgroups, at least 16 K-steps per split
+int ft_wgrad_splits(int M, int Ncol, int K, int TM, int TN, int* klen) {
+    const long long tiles = (long long)dir_cdiv(M, TM) * dir_cdiv(Ncol, TN);
+    long long splits = (1024 + tiles - 1) / tiles;
+    const long long max_splits = (K + 16 * FT_BK - 1) / (16 * FT_BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long long len = (K + splits - 1) / splits;
+    len = (len + FT_BK - 1) / FT_BK * FT_BK;
+    *klen = (int)len;
+    return (int)((K + len - 1) / len);
+}
+void ft_wgrad_tile(const ConvF32P& p, int* TM, int* TN) { *TM = p.M >= 128 ? 128 : 64; *TN = p.Ncol >= 128 ? 128 : 64; }
+
+template <int TM, int TN, int MODE>
+int ft_launch(ConvF32T q, int splits, hipStream_t s) {
+    q.ntn = dir_cdiv(q.c.Ncol, TN);
+    q.nblocks = dir_cdiv(q.c.M, TM) * q.ntn;
+    hipLaunchKernelGGL((conv_f32_tile_kernel<TM, TN, MODE>), dim3(q.nblocks, splits), dim3(DIR_TPB), 0, s, q);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
 int cf_check(const void* a, const void* b, const void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
              int* Ho, int* Wo) {
     DIR_RETURN_IF(!a || !b || !out, DIR_EINVAL);
@@ -234,18 +565,70 @@ int cf_wgrad_splits(int M, int Ncol, int K, int* klen) {
 
 }  // namespace
 
-extern "C" int dir_conv_f32_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
-                                int stride, int pad, dir_stream_t stream) {
+// variant: 0 = the product's choice (tile kernel where applicable), DIR_CONV_F32_GATHER = the element-gather kernels, DIR_CONV_F32_TILE =
+// the tile kernels (DIR_EUNSUPPORTED where they do not apply)
+static ConvF32T ft_params(const ConvF32P& p, size_t a_elems, size_t b_elems) {
+    ConvF32T q;
+    q.c = p; q.ntn = q.nblocks = 0;
+    q.kbytes_a = (int)(a_elems * 4); q.kbytes_b = (int)(b_elems * 4);
+    q.inv_wo = 1.0f / (float)p.Wo; q.inv_ho = 1.0f / (float)p.Ho;
+    q.cls = 0;
+    return q;
+}
+
+extern "C" int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                        int stride, int pad, int variant, dir_stream_t stream) {
     int Ho, Wo;
     const int rc = cf_check(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
     ConvF32P p;
     p.a = x; p.b = w; p.out = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = N * Ho * Wo; p.Ncol = Cout; p.K = R * S * Cin; p.klen = p.K;
     p.addend = p.addend2 = p.mask = nullptr;
+    const size_t xe = (size_t)N * H * W * Cin, we = (size_t)Cout * p.K;
+    const bool tile_ok = dir_aligned16(x) && dir_aligned16(w) && ft_ok(FT_FWD, p, xe, we);
+    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
+    if (tile_ok && variant != DIR_CONV_F32_GATHER) {
+        const ConvF32T q = ft_params(p, xe, we);
+        return p.Ncol > 64 ? ft_launch<128, 128, FT_FWD>(q, 1, dir_s(stream)) : ft_launch<128, 64, FT_FWD>(q, 1, dir_s(stream));
+    }
     DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535, DIR_EUNSUPPORTED);
     hipLaunchKernelGGL((conv_f32_kfast_kernel<0>), dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN)), dim3(DIR_TPB), 0, dir_s(stream), p);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+extern "C" int dir_conv_f32_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                int stride, int pad, dir_stream_t stream) {
+    return dir_conv_f32_fwd_variant(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
+}
+
+extern "C" int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
+                                          const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                          int stride, int pad, int variant, dir_stream_t stream) {
+    int Ho, Wo;
+    const int rc = cf_check(dy, w, dx, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
+    if (rc != DIR_OK) return rc;
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
+    DIR_RETURN_IF(addend_s2 && ((H | W) & 1), DIR_EUNSUPPORTED);
+    ConvF32P p;
+    p.a = dy; p.b = w; p.out = dx;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.M = N * H * W; p.Ncol = Cin; p.K = R * S * Cout; p.klen = p.K;
+    p.addend = addend; p.addend2 = addend_s2; p.mask = relu_mask;
+    const size_t ye = (size_t)N * Ho * Wo * Cout, we = (size_t)Cout * R * S * Cin;
+    const bool tile_ok = dir_aligned16(dy) && dir_aligned16(w) && ft_ok(FT_DGRAD, p, ye, we);
+    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
+    if (tile_ok && variant != DIR_CONV_F32_GATHER) {
+        ConvF32T q = ft_params(p, ye, we);
+        int zdim = 1;
+        if (stride == 2 && !((H | W) & 1)) { q.cls = 1; q.c.M = N * (H >> 1) * (W >> 1); zdim = 4; }     // four parity classes, only their own filter taps
+        return p.Ncol > 64 ? ft_launch<128, 128, FT_DGRAD>(q, zdim, dir_s(stream)) : ft_launch<128, 64, FT_DGRAD>(q, zdim, dir_s(stream));
+    }
+    DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535, DIR_EUNSUPPORTED);
+    hipLaunchKernelGGL((conv_f32_kfast_kernel<1>), dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN)), dim3(DIR_TPB), 0, dir_s(stream), p);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
@@ -253,52 +636,70 @@ extern "C" int dir_conv_f32_fwd(const float* x, const float* w, float* y, int N,
 extern "C" int dir_conv_f32_dgrad_fused(const float* dy, const float* w, const float* addend, const float* addend_s2,
                                         const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
                                         int stride, int pad, dir_stream_t stream) {
-    int Ho, Wo;
-    const int rc = cf_check(dy, w, dx, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
-    if (rc != DIR_OK) return rc;
-    DIR_RETURN_IF(addend_s2 && ((H | W) & 1), DIR_EUNSUPPORTED);
-    ConvF32P p;
-    p.a = dy; p.b = w; p.out = dx;
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.M = N * H * W; p.Ncol = Cin; p.K = R * S * Cout; p.klen = p.K;
-    p.addend = addend; p.addend2 = addend_s2; p.mask = relu_mask;
-    DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535, DIR_EUNSUPPORTED);
-    hipLaunchKernelGGL((conv_f32_kfast_kernel<1>), dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN)), dim3(DIR_TPB), 0, dir_s(stream), p);
-    DIR_LAUNCH_CHECK();
-    return DIR_OK;
+    return dir_conv_f32_dgrad_variant(dy, w, addend, addend_s2, relu_mask, dx, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
 }
 
 extern "C" int dir_conv_f32_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
                                   int stride, int pad, dir_stream_t stream) {
-    return dir_conv_f32_dgrad_fused(dy, w, nullptr, nullptr, nullptr, dx, N, H, W, Cin, Cout, R, S, stride, pad, stream);
+    return dir_conv_f32_dgrad_variant(dy, w, nullptr, nullptr, nullptr, dx, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
 }
 
+// geometry of the weight-gradient GEMM and which kernel `variant` resolves to (true = tile kernel)
+static bool cf_wgrad_plan(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int variant, ConvF32P* p, int* splits,
+                          int* TM, int* TN) {
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    p->N = N; p->H = H; p->W = W; p->Cin = Cin; p->Ho = Ho; p->Wo = Wo; p->Cout = Cout; p->R = R; p->S = S; p->stride = stride; p->pad = pad;
+    p->M = Cout; p->Ncol = R * S * Cin; p->K = N * Ho * Wo;
+    p->addend = p->addend2 = p->mask = nullptr;
+    const bool tile_ok = ft_ok(FT_WGRAD, *p, (size_t)p->K * Cout, (size_t)N * H * W * Cin);
+    const bool tile = tile_ok && variant != DIR_CONV_F32_GATHER;
+    if (tile) { ft_wgrad_tile(*p, TM, TN); *splits = ft_wgrad_splits(p->M, p->Ncol, p->K, *TM, *TN, &p->klen); }
+    else *splits = cf_wgrad_splits(p->M, p->Ncol, p->K, &p->klen);
+    return tile;
+}
+
+// (sized for whichever kernel a variant may choose: the larger of the two split counts)
 extern "C" size_t dir_conv_f32_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho <= 0 || Wo <= 0 || (long long)N * Ho * Wo >= (1ll << 31)) return 0;
-    int klen;
-    const int splits = cf_wgrad_splits(Cout, R * S * Cin, N * Ho * Wo, &klen);
-    return dir_align_up((size_t)splits * Cout * R * S * Cin * sizeof(float), 256);
+    ConvF32P p;
+    int s_tile = 0, s_gather = 0, TM, TN;
+    (void)cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, DIR_CONV_F32_GATHER, &p, &s_gather, &TM, &TN);
+    if (cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, 0, &p, &s_tile, &TM, &TN) && s_tile > s_gather) s_gather = s_tile;
+    return dir_align_up((size_t)s_gather * Cout * R * S * Cin * sizeof(float), 256);
 }
 
-extern "C" int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
-                                  int stride, int pad, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+extern "C" int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                          int stride, int pad, void* workspace, size_t workspace_bytes, int variant, dir_stream_t stream) {
     int Ho, Wo;
     const int rc = cf_check(dy, x, dw, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
     ConvF32P p;
+    int splits, TM = 64, TN = 64;
+    bool tile = cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, variant, &p, &splits, &TM, &TN);
     p.a = dy; p.b = x;
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.M = Cout; p.Ncol = R * S * Cin; p.K = N * Ho * Wo;
-    p.addend = p.addend2 = p.mask = nullptr;
-    const int splits = cf_wgrad_splits(p.M, p.Ncol, p.K, &p.klen);
-    const size_t need = dir_conv_f32_wgrad_workspace(N, H, W, Cin, Cout, R, S, stride, pad);
+    if (tile && !(dir_aligned16(dy) && dir_aligned16(x))) {
+        DIR_RETURN_IF(variant == DIR_CONV_F32_TILE, DIR_EUNSUPPORTED);
+        tile = cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, DIR_CONV_F32_GATHER, &p, &splits, &TM, &TN);
+        p.a = dy; p.b = x;
+    }
+    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile, DIR_EUNSUPPORTED);
+    const size_t need = dir_align_up((size_t)splits * Cout * R * S * Cin * sizeof(float), 256);
     DIR_RETURN_IF(splits > 1 && (!workspace || workspace_bytes < need), DIR_EWORKSPACE);
     DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535 || splits > 65535, DIR_EUNSUPPORTED);
     p.out = splits > 1 ? static_cast<float*>(workspace) : dw;
-    hipLaunchKernelGGL(conv_f32_wgrad_kernel, dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN), splits), dim3(DIR_TPB), 0, dir_s(stream), p);
-    DIR_LAUNCH_CHECK();
+    if (tile) {
+        const ConvF32T q = ft_params(p, (size_t)p.K * Cout, (size_t)N * H * W * Cin);
+        int rc2;
+        if (TM == 128) rc2 = TN == 128 ? ft_launch<128, 128, FT_WGRAD>(q, splits, dir_s(stream)) : ft_launch<128, 64, FT_WGRAD>(q, splits, dir_s(stream));
+        else rc2 = TN == 128 ? ft_launch<64, 128, FT_WGRAD>(q, splits, dir_s(stream)) : ft_launch<64, 64, FT_WGRAD>(q, splits, dir_s(stream));
+        if (rc2 != DIR_OK) return rc2;
+    } else {
+        hipLaunchKernelGGL(conv_f32_wgrad_kernel, dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN), splits), dim3(DIR_TPB), 0, dir_s(stream), p);
+        DIR_LAUNCH_CHECK();
+    }
     if (splits > 1) {
         const size_t n = (size_t)p.M * p.Ncol;
         int grid = dir_cdiv((long long)n, DIR_TPB); if (grid > 2048) grid = 2048;
@@ -306,6 +707,11 @@ extern "C" int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, in
         DIR_LAUNCH_CHECK();
     }
     return DIR_OK;
+}
+
+extern "C" int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                  int stride, int pad, void* workspace, size_t workspace_bytes, dir_stream_t stream) {
+    return dir_conv_f32_wgrad_variant(dy, x, dw, N, H, W, Cin, Cout, R, S, stride, pad, workspace, workspace_bytes, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

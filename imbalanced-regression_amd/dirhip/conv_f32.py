@@ -22,7 +22,10 @@ def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
-def conv2d_f32_fwd(x, w, stride, padding):
+GATHER, TILE = 1, 2                     # DIR_CONV_F32_GATHER / DIR_CONV_F32_TILE: force a kernel (0 = the product's choice: tile where applicable)
+
+
+def conv2d_f32_fwd(x, w, stride, padding, variant=0):
     """x [N, Cin, H, W], w [Cout, Cin, R, S]: float32 channels_last device tensors -> y float32 channels_last."""
     n, cin, h, wd = x.shape
     cout, cin2, r, s = w.shape
@@ -31,12 +34,12 @@ def conv2d_f32_fwd(x, w, stride, padding):
     wo = (wd + 2 * padding - s) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        L.check(L.lib().dir_conv_f32_fwd(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, cin, cout, r, s, stride, padding,
-                                         L.stream_ptr(x.device)), "dir_conv_f32_fwd")
+        L.check(L.lib().dir_conv_f32_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, cin, cout, r, s, stride, padding, variant,
+                                                 L.stream_ptr(x.device)), "dir_conv_f32_fwd")
     return y
 
 
-def conv2d_f32_dgrad(dy, w, in_hw, stride, padding, addend=None, addend_s2=None, relu_mask=None):
+def conv2d_f32_dgrad(dy, w, in_hw, stride, padding, addend=None, addend_s2=None, relu_mask=None, variant=0):
     """Data gradient; optionally with the fused store epilogue of the bf16 path (``dir_conv_f32_dgrad_fused``):
     ``+ addend`` (same shape as dx), ``+ addend_s2`` (compact ``[N, Cin, H/2, W/2]``, added at the even pixels) and the
     ReLU backward ``* (relu_mask > 0)``."""
@@ -47,13 +50,13 @@ def conv2d_f32_dgrad(dy, w, in_hw, stride, padding, addend=None, addend_s2=None,
     for t, shp in ((addend, (n, cin, h, wd)), (relu_mask, (n, cin, h, wd)), (addend_s2, (n, cin, h // 2, wd // 2))):
         assert t is None or (tuple(t.shape) == shp and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)), shp
     with torch.cuda.device(dy.device):
-        L.check(L.lib().dir_conv_f32_dgrad_fused(L.ptr(dy), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(dx),
-                                                 n, h, wd, cin, cout, r, s, stride, padding, L.stream_ptr(dy.device)),
+        L.check(L.lib().dir_conv_f32_dgrad_variant(L.ptr(dy), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(dx),
+                                                   n, h, wd, cin, cout, r, s, stride, padding, variant, L.stream_ptr(dy.device)),
                 "dir_conv_f32_dgrad")
     return dx
 
 
-def conv2d_f32_wgrad(dy, x, kernel_hw, stride, padding):
+def conv2d_f32_wgrad(dy, x, kernel_hw, stride, padding, variant=0):
     n, cin, h, wd = x.shape
     cout = dy.shape[1]
     r, s = kernel_hw
@@ -63,8 +66,8 @@ def conv2d_f32_wgrad(dy, x, kernel_hw, stride, padding):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        L.check(L.lib().dir_conv_f32_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, wd, cin, cout, r, s, stride, padding, L.ptr(ws),
-                                           ws.numel(), L.stream_ptr(x.device)), "dir_conv_f32_wgrad")
+        L.check(L.lib().dir_conv_f32_wgrad_variant(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, wd, cin, cout, r, s, stride, padding, L.ptr(ws),
+                                                   ws.numel(), variant, L.stream_ptr(x.device)), "dir_conv_f32_wgrad")
     return dw
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIR_ABI_VERSION 2
+#define DIR_ABI_VERSION 3
 
 #define DIR_OK            0
 #define DIR_EINVAL       (-1)   /* bad argument (null pointer, non-positive size, ks even, ...) */
@@ -548,6 +548,20 @@ int dir_conv_f32_dgrad_fused(const float* dy, const float* w, const float* adden
 size_t dir_conv_f32_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
 int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
                        int stride, int pad, void* workspace, size_t workspace_bytes, dir_stream_t stream);
+/* The same three with the kernel forced (ABI 3; tests and A/B measurements).  variant 0 = the product's choice: the TILE kernels
+ * (128 x 128 workgroup tile, 64 x 64 per wavefront, LDS-DMA operand staging, two LDS stages; 4x the gather kernels' rate) wherever
+ * the K axis comes in whole 16-channel steps (Cin resp. Cout % 16 == 0; weight gradient: channels % 4 == 0), the element-GATHER
+ * kernels otherwise (7x7 stem, odd channel counts).  Forward and data gradient of the two are bit-identical (same k order on the
+ * same MFMA); the weight gradients differ in their split-K boundaries.  DIR_EUNSUPPORTED: variant TILE on a geometry it does not take. */
+#define DIR_CONV_F32_GATHER 1
+#define DIR_CONV_F32_TILE 2
+int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                             int stride, int pad, int variant, dir_stream_t stream);
+int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
+                               const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
+                               int stride, int pad, int variant, dir_stream_t stream);
+int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
+                               int stride, int pad, void* workspace, size_t workspace_bytes, int variant, dir_stream_t stream);
 /* float32 NHWC pools of the parity mode: MaxPool2d(3, 2, 1) with an argmax byte (resnet.py:82,131) and the global
  * average pool (resnet.py:85,136-137; sequential window sum / HW like torch's AvgPool2d). */
 int dir_maxpool3x3s2_f32_fwd(const float* x, float* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);

@@ -46,6 +46,68 @@ def test_conv_f32_fwd_dgrad_wgrad_vs_float64(case):
     assert_close(dw.cpu().numpy(), wd.grad.numpy(), rtol=1e-5, atol_scale=2e-6, msg=f"wgrad {case}")
 
 
+TILE_CASES = [  # (N, Cin, H, W, Cout, k, stride, pad): geometries the tile kernels take (whole 16-channel K-steps)
+    (2, 64, 14, 14, 64, 1, 1, 0), (2, 64, 15, 13, 128, 1, 2, 0), (3, 64, 14, 14, 64, 3, 2, 1), (2, 32, 9, 11, 48, 3, 1, 1),
+    (1, 128, 7, 7, 256, 3, 1, 1), (2, 64, 8, 8, 64, 3, 2, 1), (1, 256, 7, 5, 64, 1, 1, 0), (5, 16, 5, 3, 16, 3, 2, 1),
+    (3, 256, 14, 14, 1024, 1, 1, 0), (2, 512, 7, 7, 512, 3, 1, 1), (2, 128, 28, 28, 128, 3, 2, 1), (1, 64, 1, 1, 64, 1, 1, 0),
+    (2, 48, 10, 6, 80, 3, 1, 1),            # ragged tiles in every direction (Cout = 80, M = 120)
+    (2, 32, 12, 10, 32, 1, 2, 0),           # 1x1 stride 2: three of the four parity classes of the data gradient have no tap (zeros)
+    (2, 16, 9, 7, 32, 3, 2, 1),             # stride 2 on an odd-sized map: the masked (not the parity-class) data gradient
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES)
+def test_conv_f32_tile_kernels_vs_gather_and_float64(case):
+    """Round 6: the 128 x 128 tile kernels (LDS-DMA staging, two stages) against (a) the element-gather kernels — forward and data
+    gradient BIT-IDENTICAL (same k order on the same MFMA), also with the fused store epilogue (addend, compact stride-2 addend, ReLU
+    mask) — and (b) float64 torch-CPU references of all three GEMMs at the float32 accumulation-noise tolerance."""
+    from dirhip.conv_f32 import GATHER, TILE, conv2d_f32_dgrad, conv2d_f32_fwd, conv2d_f32_wgrad
+    n, cin, h, w, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) * 11 + 3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, None, stride, pad)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)     # noqa: E731
+    xg, wg, dyg = cl(x), cl(wt), cl(dy)
+    y_t, y_g = conv2d_f32_fwd(xg, wg, stride, pad, variant=TILE), conv2d_f32_fwd(xg, wg, stride, pad, variant=GATHER)
+    assert torch.equal(y_t, y_g), f"fwd tile != gather {case}: {(y_t - y_g).abs().max().item()}"
+    assert torch.equal(conv2d_f32_fwd(xg, wg, stride, pad), y_t)              # the product's choice is the tile kernel here
+    assert_close(y_t.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol_scale=2e-6, msg=f"fwd {case}")
+    dx_t = conv2d_f32_dgrad(dyg, wg, (h, w), stride, pad, variant=TILE)
+    dx_g = conv2d_f32_dgrad(dyg, wg, (h, w), stride, pad, variant=GATHER)
+    assert torch.equal(dx_t, dx_g), f"dgrad tile != gather {case}: {(dx_t - dx_g).abs().max().item()}"
+    assert_close(dx_t.cpu().numpy(), xd.grad.numpy(), rtol=1e-5, atol_scale=2e-6, msg=f"dgrad {case}")
+    # fused store epilogue
+    add = cl(torch.randn(n, cin, h, w, generator=g))
+    msk = cl(torch.randn(n, cin, h, w, generator=g))
+    kw = dict(addend=add, relu_mask=msk)
+    if h % 2 == 0 and w % 2 == 0:
+        kw["addend_s2"] = cl(torch.randn(n, cin, h // 2, w // 2, generator=g))
+    f_t = conv2d_f32_dgrad(dyg, wg, (h, w), stride, pad, variant=TILE, **kw)
+    f_g = conv2d_f32_dgrad(dyg, wg, (h, w), stride, pad, variant=GATHER, **kw)
+    assert torch.equal(f_t, f_g), f"fused dgrad tile != gather {case}"
+    exp = dx_t + add
+    if "addend_s2" in kw:
+        exp[:, :, ::2, ::2] += kw["addend_s2"]
+    assert torch.equal(f_t, torch.where(msk > 0, exp, torch.zeros_like(exp)))
+    dw_t = conv2d_f32_wgrad(dyg, xg, (k, k), stride, pad, variant=TILE)
+    assert_close(dw_t.cpu().numpy(), wd.grad.numpy(), rtol=1e-5, atol_scale=2e-6, msg=f"wgrad {case}")
+    assert torch.equal(conv2d_f32_wgrad(dyg, xg, (k, k), stride, pad, variant=TILE), dw_t)       # fixed-order split-K: reproducible
+
+
+def test_conv_f32_tile_variant_refuses_what_it_does_not_take():
+    from dirhip import _lib as L
+    from dirhip.conv_f32 import TILE, conv2d_f32_fwd
+    x = torch.randn(2, 3, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)          # the stem: Cin = 3
+    w = torch.randn(64, 3, 7, 7, device="cuda").contiguous(memory_format=torch.channels_last)
+    with pytest.raises(L.DirHipError):
+        conv2d_f32_fwd(x, w, 2, 3, variant=TILE)
+    assert conv2d_f32_fwd(x, w, 2, 3).shape == (2, 64, 8, 8)                                            # auto: the gather kernel
+
+
 def test_conv_f32_autograd_node_and_determinism():
     """conv_f32 (the autograd node resnet.py uses in parity mode) == F.conv2d in float64, also for a bf16 caller (casts
     around the float32 kernels), and two runs are bit-identical (fixed-order split-K, no atomics)."""
