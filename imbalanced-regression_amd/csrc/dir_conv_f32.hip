@@ -504,8 +504,8 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
 }
 
 // (A form of the forward kernel with a dedicated LOADER wavefront — wavefront 4 issues all DMA pieces, wavefronts 0-3 only MFMAs — was built,
-// bit-identical, and measured 3-40 % SLOWER on every ResNet-50 layer: profiles/r06_f32_loader_wave_negative.txt; code at the commit before this
-// one. The phase ablation that motivated it: profiles/r06_f32_tile_phase_ablation.txt — time ~ MFMA-only + 0.7 x DMA-only, unchanged without
+// bit-identical, and measured 3-40 % SLOWER on every ResNet-50 layer (profiles/r06_f32_loader_wave_negative.txt) and not kept. The phase
+// ablation that motivated it: profiles/r06_f32_tile_phase_ablation.txt — time ~ MFMA-only + 0.7 x DMA-only, unchanged without
 // barriers / DMA waits.)
 // Is the tile kernel applicable? (whole 16-channel K-steps, 16-byte columns, 32-bit byte offsets; the weight gradient's pixel decode is
 // exact below 2^24 pixels)
@@ -516,10 +516,11 @@ bool ft_ok(int mode, const ConvF32P& p, size_t a_elems, size_t b_elems) {
     return p.Cout % 4 == 0 && p.Cin % 4 == 0 && p.K < (1 << 24);
 }
 
-// split-K of the weight gradient on TM x TN tiles: ~1024 workgroups, at least 16 K-steps per split
+// split-K of the weight gradient on TM x TN tiles: ~FT_WGRAD_WGS workgroups, at least 16 K-steps per split
+constexpr int FT_WGRAD_WGS = 768;
 int ft_wgrad_splits(int M, int Ncol, int K, int TM, int TN, int* klen) {
     const long long tiles = (long long)dir_cdiv(M, TM) * dir_cdiv(Ncol, TN);
-    long long splits = (1024 + tiles - 1) / tiles;
+    long long splits = (FT_WGRAD_WGS + tiles - 1) / tiles;
     const long long max_splits = (K + 16 * FT_BK - 1) / (16 * FT_BK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -525,6 +525,11 @@ def _refresh_all(device):
         st.key = _weight_key(w)
 
 
+def registry_size(device):
+    """Number of conv layers with bf16 operand buffers on ``device`` (grows when a float32-mode run switches to bf16)."""
+    return len(_REGISTRY.get(device, []))
+
+
 def prepared_operands(device):
     """{master weight address: _PreparedWeights} of the live conv layers on ``device`` whose bf16 operands the optimizer kernel may
     rewrite itself (``dirhip.optim.Adam``): float32 channels_last weights of the registered layers."""

@@ -97,7 +97,7 @@ class Adam(torch.optim.Adam):
                 elif s != step:
                     raise L.DirHipError("dirhip.optim.Adam: parameters of one group with different step counts")
             dev = params[0].device
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in params)
+            key = (_conv.registry_size(dev),) + tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in params)
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
                 prepared = _conv.prepared_operands(dev)                     # master-weight address -> the layer's bf16 operand buffers
@@ -201,7 +201,7 @@ class SGD(torch.optim.SGD):
                     new_bufs = [torch.empty_like(p, memory_format=torch.preserve_format) for p in params]
             dev = params[0].device
             bufs = new_bufs if new_bufs is not None else [self.state[p]["momentum_buffer"] if mom != 0.0 else None for p in params]
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), 0 if b is None else b.data_ptr()) for p, b in zip(params, bufs))
+            key = (_conv.registry_size(dev),) + tuple((p.data_ptr(), p.grad.data_ptr(), 0 if b is None else b.data_ptr()) for p, b in zip(params, bufs))
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
                 prepared = _conv.prepared_operands(dev)

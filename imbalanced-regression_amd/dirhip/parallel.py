@@ -143,6 +143,13 @@ class DataParallelEngine(nn.Module):
             if force_collectives:
                 fds.force_collectives = True
 
+    def set_amp_dtype(self, amp_dtype):
+        """Switch the conv stack's arithmetic between runs of the SAME graph: ``torch.bfloat16`` (bf16 MFMA kernels under autocast) or None
+        (exact-float32 MFMA kernels). Takes effect at the next forward pass; master weights, optimizer state, BatchNorm / FDS buffers are shared
+        (``train.py --amp_switch_epoch``)."""
+        assert amp_dtype in (None, torch.bfloat16)
+        self.amp_dtype = amp_dtype
+
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, inputs, *args, **kwargs):
         if self.training and torch.is_grad_enabled() and (self._comm or inputs.is_cuda):
