@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
     constexpr int WM = TM / WGM, WN = TN / WGN, MI = WM / 32, NI = WN / 32;
     constexpr int NA = TM / 64, NB = TN / 64;                       // 1 KB DMA pieces per wavefront and K-step
     constexpr int A_BYTES = TM * FT_ROWB, STAGE = (TM + TN) * FT_ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int LDS_BYTES = (2 * STAGE > 64 * TN * 4) ? 2 * STAGE : 64 * TN * 4;     // two K-loop stages; the epilogue's 64-row slab
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     int lin;
     {
         const int b = blockIdx.x, n8 = q.nblocks / 8, r8 = q.nblocks % 8, xcd = b % 8, i = b / 8;
@@ -465,7 +466,10 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
         }
     }
 
-    // ---- store (C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
+    // ---- store. C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds ONE column, so
+    // storing from the accumulators is 4 bytes per lane (and the fused addend / mask reads likewise). The tile goes through the (now free) K-loop
+    // LDS instead, 64 rows at a time ([64][TN] floats: the two stages' bytes at 128 x 128): written column-per-lane, read back row-wise as float4 —
+    // 16-byte global accesses, whole 512-byte rows per half-wavefront, a quarter of the memory instructions.
     float* out = MODE == FT_WGRAD ? p.out + (size_t)blockIdx.y * p.M * p.Ncol : p.out;
     if (FT_ABLATE == 2) {
         float s_ = 0.0f;
@@ -474,6 +478,63 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
         return;
     }
     const bool fused = MODE == FT_DGRAD && (p.addend || p.addend2 || p.mask);
+    auto map_row = [&](int row) {                                   // parity-class data gradient: class row (img, i, j) -> pixel (2 i + a, 2 j + b)
+        if (MODE == FT_DGRAD && q.cls) {
+            const int w2 = p.W >> 1, h2 = p.H >> 1, j = row % w2, qq = row / w2, i = qq % h2, img = qq / h2;
+            row = (img * p.H + 2 * i + cls_a) * p.W + 2 * j + cls_b;
+        }
+        return row;
+    };
+    if ((p.Ncol & 3) == 0) {
+        float* slab = reinterpret_cast<float*>(smem);
+        constexpr int C4 = TN / 4, RPI = DIR_TPB / C4;              // float4 per row, rows per pass of the 256 threads
+        const int c4 = t % C4, r4 = t / C4;
+        const int col = n0 + 4 * c4;
+#pragma unroll
+        for (int h = 0; h < TM / 64; ++h) {
+            if ((wm * WM) / 64 == h) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            slab[(wm * WM - 64 * h + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * TN + wn * WN + ni * 32 + fi] = acc[mi][ni][e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int lr = it * RPI + r4;
+                int row = m0 + 64 * h + lr;
+                if (row < p.M && col < p.Ncol) {
+                    row = map_row(row);
+                    const size_t o = (size_t)row * p.Ncol + col;
+                    float4 v = *reinterpret_cast<const float4*>(slab + lr * TN + 4 * c4);
+                    if (fused) {
+                        if (p.addend) { const float4 a4 = *reinterpret_cast<const float4*>(p.addend + o); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+                        if (p.addend2) {
+                            const int w = row % p.W, qq = row / p.W, hh = qq % p.H, n = qq / p.H;
+                            if (!((hh | w) & 1)) {
+                                const float4 a4 = *reinterpret_cast<const float4*>(p.addend2 + (((size_t)n * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (w >> 1)) * p.Ncol + col);
+                                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                            }
+                        }
+                        if (p.mask) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(p.mask + o);
+                            if (!(m4.x > 0.0f)) v.x = 0.0f;
+                            if (!(m4.y > 0.0f)) v.y = 0.0f;
+                            if (!(m4.z > 0.0f)) v.z = 0.0f;
+                            if (!(m4.w > 0.0f)) v.w = 0.0f;
+                        }
+                    }
+                    *reinterpret_cast<float4*>(out + o) = v;
+                }
+            }
+            if (h + 1 < TM / 64) __syncthreads();
+        }
+        return;
+    }
+    // (column counts that are not multiples of 4: from the accumulators)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = n0 + wn * WN + ni * 32 + fi;
@@ -484,17 +545,14 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
             for (int e = 0; e < 16; ++e) {
                 int row = m0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                 if (row >= p.M) continue;
-                if (MODE == FT_DGRAD && q.cls) {                    // class row (img, i, j) -> pixel (2 i + a, 2 j + b)
-                    const int w2 = p.W >> 1, h2 = p.H >> 1, j = row % w2, qq = row / w2, i = qq % h2, img = qq / h2;
-                    row = (img * p.H + 2 * i + cls_a) * p.W + 2 * j + cls_b;
-                }
+                row = map_row(row);
                 const size_t o = (size_t)row * p.Ncol + col;
                 float v = acc[mi][ni][e];
                 if (fused) {
                     if (p.addend) v += p.addend[o];
                     if (p.addend2) {
-                        const int w = row % p.W, qq = row / p.W, h = qq % p.H, n = qq / p.H;
-                        if (!((h | w) & 1)) v += p.addend2[(((size_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Ncol + col];
+                        const int w = row % p.W, qq = row / p.W, hh = qq % p.H, n = qq / p.H;
+                        if (!((hh | w) & 1)) v += p.addend2[(((size_t)n * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (w >> 1)) * p.Ncol + col];
                     }
                     if (p.mask && !(p.mask[o] > 0.0f)) v = 0.0f;
                 }

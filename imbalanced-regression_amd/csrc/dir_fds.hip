@@ -70,18 +70,20 @@ extern "C" int dir_fds_bin_index(const float* labels, int n, int bucket_start, i
 // K2: per-bin (count, mean, M2) in one streaming pass
 // =============================================================================================
 // Stage G1-G3: stable counting sort of the row indices by bin (rows with bin < 0 dropped).
-//   tile  = GROUP_TILE consecutive rows handled by ONE wavefront (so ranks inside a tile come from
+//   tile  = GROUP_TILE consecutive rows handled by ONE workgroup, a quarter per wavefront (ranks inside a wavefront's rows come from
 //           ballots in program order: stable and deterministic without atomics on the data path);
 // Stage P : every "piece" (<= PIECE_ROWS sorted rows of one bin) x (column tile) is reduced in
 //           float64 registers around the shift K = first row of the bin;
 // Stage C : pieces of a bin are combined in index order -> (count, mean, M2).
-#define GROUP_TILE 256        // rows per grouping wavefront: N / 256 wavefronts keep all 256 CUs busy at N = 191 509
+#define GROUP_WAVES 4
+#define GROUP_WROWS 1024      // rows per grouping wavefront
+#define GROUP_TILE (GROUP_WAVES * GROUP_WROWS)   // rows per grouping workgroup (tile): few enough tiles that the prefix over tiles is one LDS-resident scan
 #define PIECE_ROWS 256        // rows per piece: 2 x fewer float64 partials to write and re-read than 128 (52 -> 26 MB at N = 191 509)
 #define PIECE_UNROLL 8
 
 struct ScatterWs {            // carved from the caller's workspace (all 256-B aligned)
     int32_t* tile_hist;       // [ntiles][nb]   counts, then exclusive prefix over tiles
-    int32_t* totals;          // [nb]           rows per bin
+    int32_t* totals;          // [nb]           (unused since round 6)
     int32_t* offsets;         // [nb+1]         start of each bin in perm
     int32_t* bin_piece0;      // [nb+1]         first piece of each bin
     int32_t* npieces;         // [1]
@@ -125,65 +127,75 @@ extern "C" size_t dir_fds_scatter_stats_workspace(int n, int C, int nb) {
     return carve_ws(nullptr, n, C, nb).bytes;
 }
 
-// G1: one wavefront per tile; LDS histogram.
-__global__ void __launch_bounds__(DIR_WAVE)
+// G1: one workgroup (4 wavefronts) per tile of GROUP_TILE rows; per-wavefront LDS histograms (each wavefront owns a quarter of the tile, in row
+// order), summed to the tile's counts. Round 6: tiles of 4096 rows instead of 256-row wavefront tiles — 136 instead of 2 166 tiles at the NYUD2
+// map's N = 554 496 — so that the prefix over tiles (G2) is ONE small LDS-resident scan instead of two latency-bound launches
+// (profiles/r05_fds_scatter_narrow_breakdown.txt: 19 of the call's 93 us).
+__global__ void __launch_bounds__(DIR_TPB)
 fds_group_hist_kernel(const int32_t* __restrict__ bins, int n, int nb, int32_t* __restrict__ tile_hist) {
-    extern __shared__ __attribute__((aligned(16))) int32_t hist[];
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int b = lane; b < nb; b += DIR_WAVE) hist[b] = 0;
+    extern __shared__ __attribute__((aligned(16))) int32_t hist[];       // [GROUP_WAVES][nb]
+    const int t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE, tile = blockIdx.x;
+    for (int i = t; i < GROUP_WAVES * nb; i += DIR_TPB) hist[i] = 0;
     __syncthreads();
-    const int r0 = tile * GROUP_TILE;
-    for (int r = r0 + lane; r < min(n, r0 + GROUP_TILE); r += DIR_WAVE) {
+    const int r0 = tile * GROUP_TILE + wid * GROUP_WROWS;
+    const int r1 = min(n, r0 + GROUP_WROWS);
+    for (int r = r0 + lane; r < r1; r += DIR_WAVE) {
         const int b = bins[r];
-        if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);        // LDS integer atomic: order-free
+        if (b >= 0 && b < nb) atomicAdd(&hist[wid * nb + b], 1);          // LDS integer atomic: order-free
     }
     __syncthreads();
-    for (int b = lane; b < nb; b += DIR_WAVE) tile_hist[(size_t)tile * nb + b] = hist[b];
-}
-
-// G2a: one workgroup per bin: exclusive prefix of that bin's counts over the tiles (parallel scan: wave shuffles +
-// LDS carry), total per bin.
-__global__ void __launch_bounds__(DIR_TPB)
-fds_group_scan_tiles_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int32_t* __restrict__ totals) {
-    __shared__ int32_t wsum[DIR_TPB / DIR_WAVE];
-    __shared__ int32_t carry_sh;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE;
-    if (t == 0) carry_sh = 0;
-    __syncthreads();
-    for (int base = 0; base < ntiles; base += DIR_TPB) {
-        const int tile = base + t;
-        const int c = tile < ntiles ? tile_hist[(size_t)tile * nb + b] : 0;
-        int incl = c;                                      // inclusive scan inside the wavefront
+    for (int b = t; b < nb; b += DIR_TPB) {
+        int c = 0;
 #pragma unroll
-        for (int o = 1; o < DIR_WAVE; o <<= 1) { const int v = __shfl_up(incl, o, DIR_WAVE); if (lane >= o) incl += v; }
-        if (lane == DIR_WAVE - 1) wsum[wid] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wid; ++k) woff += wsum[k];
-        const int carry = carry_sh;
-        if (tile < ntiles) tile_hist[(size_t)tile * nb + b] = carry + woff + incl - c;
-        __syncthreads();
-        if (t == DIR_TPB - 1) carry_sh = carry + woff + incl;
-        __syncthreads();
+        for (int w2 = 0; w2 < GROUP_WAVES; ++w2) c += hist[w2 * nb + b];
+        tile_hist[(size_t)tile * nb + b] = c;
     }
-    if (t == 0) totals[b] = carry_sh;
 }
 
-// G2b: single workgroup: offsets over bins, piece table.
-__global__ void __launch_bounds__(DIR_TPB)
-fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
+// G2: ONE workgroup: the tile counts [ntiles][nb] are brought into LDS by slabs of tiles, turned into exclusive prefixes over the tiles per
+// bin (thread = bin, a running carry per bin across the slabs) and written back; then the offsets over bins and the piece table.
+#define GROUP_SCAN_TPB 1024
+__global__ void __launch_bounds__(GROUP_SCAN_TPB)
+fds_group_scan_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int slab_tiles, int maxpieces,
                       int32_t* __restrict__ offsets, int32_t* __restrict__ bin_piece0,
                       int32_t* __restrict__ npieces, int32_t* __restrict__ piece_bin,
                       int32_t* __restrict__ piece_p0, int32_t* __restrict__ piece_p1) {
-    extern __shared__ __attribute__((aligned(16))) int32_t sh[];     // totals[nb+1], pieces[nb+1]
-    int32_t* tot = sh;
-    int32_t* pcs = sh + (nb + 1);
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) pcs[b] = totals[b];     // parallel fetch: the serial scan below then runs on LDS
+    extern __shared__ __attribute__((aligned(16))) int32_t sh[];         // slab[slab_tiles][nb], carry[nb], tot[nb + 1], pcs[nb + 1]
+    int32_t* slab = sh;
+    int32_t* carry = sh + (size_t)slab_tiles * nb;
+    int32_t* tot = carry + nb;
+    int32_t* pcs = tot + (nb + 1);
+    const int t = threadIdx.x;
+    for (int b = t; b < nb; b += GROUP_SCAN_TPB) carry[b] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {                                // nb is a few hundred at most
+    for (int t0 = 0; t0 < ntiles; t0 += slab_tiles) {
+        const int nt = min(slab_tiles, ntiles - t0);
+        const int cnt = nt * nb;
+        __syncthreads();
+        for (int i = t; i < cnt; i += GROUP_SCAN_TPB) slab[i] = tile_hist[(size_t)t0 * nb + i];      // contiguous: all loads independent
+        __syncthreads();
+        for (int b = t / DIR_WAVE; b < nb; b += GROUP_SCAN_TPB / DIR_WAVE) {                          // one wavefront per bin, lanes over the slab's tiles
+            const int lane = t & (DIR_WAVE - 1);
+            int c = carry[b];
+            for (int k0 = 0; k0 < nt; k0 += DIR_WAVE) {
+                const int k = k0 + lane;
+                const int v = k < nt ? slab[k * nb + b] : 0;
+                int incl = v;
+#pragma unroll
+                for (int o = 1; o < DIR_WAVE; o <<= 1) { const int u = __shfl_up(incl, o, DIR_WAVE); if (lane >= o) incl += u; }
+                if (k < nt) slab[k * nb + b] = c + incl - v;
+                c += __shfl(incl, DIR_WAVE - 1, DIR_WAVE);
+            }
+            if (lane == 0) carry[b] = c;
+        }
+        __syncthreads();
+        for (int i = t; i < cnt; i += GROUP_SCAN_TPB) tile_hist[(size_t)t0 * nb + i] = slab[i];
+    }
+    __syncthreads();
+    if (t == 0) {                                          // nb is a few thousand at most
         int o = 0, p = 0;
         for (int b = 0; b < nb; ++b) {
-            const int c = pcs[b];
+            const int c = carry[b];
             offsets[b] = o; bin_piece0[b] = p;
             tot[b] = o; pcs[b] = p;
             o += c; p += (c + PIECE_ROWS - 1) / PIECE_ROWS;
@@ -192,7 +204,7 @@ fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
         *npieces = p;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    for (int b = t; b < nb; b += GROUP_SCAN_TPB) {
         const int o0 = tot[b], o1 = tot[b + 1];
         int k = pcs[b];
         for (int p0 = o0; p0 < o1; p0 += PIECE_ROWS, ++k) {
@@ -201,24 +213,39 @@ fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
     }
 }
 
-// G3: one wavefront per tile; stable placement. For each chunk of 64 rows the lanes that share a bin are found with one
+// G3: one workgroup per tile; stable placement. The wavefronts of a tile own consecutive quarters of its rows: wavefront w starts every bin's
+// cursor at (bin offset) + (rows of that bin in earlier tiles) + (rows of that bin in wavefronts < w of this tile) — the per-wavefront
+// histograms are recounted here (16 KB of bins per tile, L2 resident). For each chunk of 64 rows the lanes that share a bin are found with one
 // ballot per BIT of the bin index ("match-any": 7 ballots for 100 bins, no loop over the distinct bins of the chunk, no
 // barrier), the lowest such lane bumps the bin's cursor once (LDS atomic of ONE lane per bin and chunk, chunks in program
 // order: the result is the stable order, independent of timing) and every lane stores its row at base + (number of lower
-// lanes of its bin). Round 1 looped over the distinct bins of a chunk with two barriers each: 22-27 us, latency bound.
-__global__ void __launch_bounds__(DIR_WAVE)
+// lanes of its bin).
+__global__ void __launch_bounds__(DIR_TPB)
 fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbits,
                        const int32_t* __restrict__ tile_prefix, const int32_t* __restrict__ offsets,
                        int32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int32_t cursor[];
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int b = lane; b < nb; b += DIR_WAVE) cursor[b] = offsets[b] + tile_prefix[(size_t)tile * nb + b];
+    extern __shared__ __attribute__((aligned(16))) int32_t cursor[];     // [GROUP_WAVES][nb]
+    const int t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE, tile = blockIdx.x;
+    for (int i = t; i < GROUP_WAVES * nb; i += DIR_TPB) cursor[i] = 0;
     __syncthreads();
-    const int r0 = tile * GROUP_TILE;
+    const int r0 = tile * GROUP_TILE + wid * GROUP_WROWS;
+    const int r1 = min(n, r0 + GROUP_WROWS);
+    for (int r = r0 + lane; r < r1; r += DIR_WAVE) {
+        const int b = bins[r];
+        if (b >= 0 && b < nb) atomicAdd(&cursor[wid * nb + b], 1);
+    }
+    __syncthreads();
+    for (int b = t; b < nb; b += DIR_TPB) {                              // counts -> start cursors of the four wavefronts
+        int c = offsets[b] + tile_prefix[(size_t)tile * nb + b];
+#pragma unroll
+        for (int w2 = 0; w2 < GROUP_WAVES; ++w2) { const int v = cursor[w2 * nb + b]; cursor[w2 * nb + b] = c; c += v; }
+    }
+    __syncthreads();
+    int32_t* cur = cursor + wid * nb;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int c = 0; c < GROUP_TILE; c += DIR_WAVE) {
-        const int r = r0 + c + lane;
-        int b = (r < n) ? bins[r] : -1;
+    for (int c = r0; c < r1; c += DIR_WAVE) {
+        const int r = c + lane;
+        int b = (r < r1) ? bins[r] : -1;
         if (b >= nb) b = -1;
         const bool valid = b >= 0;
         unsigned long long mask = __ballot(valid);
@@ -230,11 +257,10 @@ fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbit
         if (valid) {                                            // mask = the valid lanes of this chunk with my bin
             const int leader = __ffsll((long long)mask) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&cursor[b], __popcll(mask));
+            if (lane == leader) base = atomicAdd(&cur[b], __popcll(mask));
             base = __shfl(base, leader, DIR_WAVE);
             perm[base + __popcll(mask & lt)] = r;
         }
-        if (r0 + c + DIR_WAVE >= n) break;
     }
 }
 
@@ -397,20 +423,25 @@ extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t
     ScatterWs w = carve_ws(workspace, n, C, nb);
     DIR_RETURN_IF(workspace_bytes < w.bytes, DIR_EWORKSPACE);
     const float* f = static_cast<const float*>(feats);
-    const size_t lds_nb = sizeof(int32_t) * (size_t)nb;
-    DIR_RETURN_IF(2 * (lds_nb + 4) > 64 * 1024, DIR_EUNSUPPORTED);
-
-    hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s, bins, n, nb, w.tile_hist);
+    const size_t lds_nb = sizeof(int32_t) * (size_t)nb * GROUP_WAVES;
+    DIR_RETURN_IF(lds_nb > 128 * 1024, DIR_EUNSUPPORTED);                        // (nb <= 8192: one LDS counter per bin and grouping wavefront)
+    DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_TPB), lds_nb, s, bins, n, nb, w.tile_hist);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fds_group_scan_tiles_kernel, dim3(nb), dim3(DIR_TPB), 0, s, w.tile_hist, w.ntiles, nb, w.totals);
-    DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(DIR_TPB), 2 * (lds_nb + sizeof(int32_t)), s,
-                       w.totals, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
+    // the scan keeps a slab of tiles + 3 bin-sized arrays in LDS: as many tiles per slab as fit 150 KB
+    int slab_tiles = (int)((150 * 1024 / sizeof(int32_t) - 3 * (size_t)(nb + 1)) / (size_t)nb);
+    if (slab_tiles > w.ntiles) slab_tiles = w.ntiles;
+    DIR_RETURN_IF(slab_tiles < 1, DIR_EUNSUPPORTED);
+    const size_t lds_scan = sizeof(int32_t) * ((size_t)slab_tiles * nb + 3 * (size_t)(nb + 1));
+    hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(GROUP_SCAN_TPB), lds_scan, s,
+                       w.tile_hist, w.ntiles, nb, slab_tiles, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
                        w.piece_bin, w.piece_p0, w.piece_p1);
     DIR_LAUNCH_CHECK();
     int nbits = 0;
     while ((1 << nbits) < nb) ++nbits;
-    hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s,
+    hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_TPB), lds_nb, s,
                        bins, n, nb, nbits, w.tile_hist, w.offsets, w.perm);
     DIR_LAUNCH_CHECK();
     const bool vec4 = (C % 4 == 0) && dir_aligned16(feats);
@@ -476,6 +507,65 @@ extern "C" int dir_fds_finalize_update(const double* count, const double* mean, 
     DIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(fds_finalize_tracked_kernel, dim3(dir_cdiv(nb, DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream),
                        count, nb, num_samples_tracked);
+    DIR_LAUNCH_CHECK();
+    return DIR_OK;
+}
+
+// K3 for NON-INTEGER labels (fds.py:91-111 iterates torch.unique(labels): ONE blend per distinct label VALUE, in ascending order, into
+// bin int(value - bucket_start)). The statistics arrive per value GROUP (count / mean / m2 [U], groups sorted by value, so the groups of a bin are
+// the contiguous range bin_ptr[b] .. bin_ptr[b + 1]); a thread owns one (bin, column) and applies the bin's blends one after the other, with the
+// running num_samples_tracked the count-based factor is made from (fds.py:104-106) advancing group by group.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_finalize_groups_tables_kernel(const double* __restrict__ count, const double* __restrict__ mean, const double* __restrict__ m2, int C,
+                                  const int32_t* __restrict__ bin_ptr, int factor_mode, double momentum,
+                                  float* __restrict__ running_mean, float* __restrict__ running_var, const float* __restrict__ tracked) {
+    const int b = blockIdx.x;
+    const int g0 = bin_ptr[b], g1 = bin_ptr[b + 1];
+    if (g0 >= g1) return;
+    for (int col = blockIdx.y * DIR_TPB + threadIdx.x; col < C; col += gridDim.y * DIR_TPB) {
+        const size_t ob = (size_t)b * C + col;
+        float rm = running_mean[ob], rv = running_var[ob], tr = tracked[b];
+        for (int g = g0; g < g1; ++g) {
+            const double n = count[g];
+            if (n <= 0.0) continue;
+            tr = tr + (float)n;                                            // fds.py:104 (float32 buffer)
+            double factor;
+            if (factor_mode == DIR_FACTOR_ZERO) factor = 0.0;
+            else if (factor_mode == DIR_FACTOR_MOMENTUM) factor = momentum;
+            else factor = 1.0 - n / (double)tr;                            // fds.py:105-106
+            const float a = (float)(1.0 - factor), f = (float)factor;
+            const size_t og = (size_t)g * C + col;
+            const float cm = (float)mean[og];
+            const float cv = (n == 1.0) ? 0.0f : (float)(m2[og] / (n - 1.0));   // fds.py:102
+            rm = a * cm + f * rm;
+            rv = a * cv + f * rv;
+        }
+        running_mean[ob] = rm;
+        running_var[ob] = rv;
+    }
+}
+
+__global__ void fds_finalize_groups_tracked_kernel(const double* __restrict__ count, const int32_t* __restrict__ bin_ptr, int nb,
+                                                   float* __restrict__ tracked) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    float tr = tracked[b];
+    for (int g = bin_ptr[b]; g < bin_ptr[b + 1]; ++g)
+        if (count[g] > 0.0) tr = tr + (float)count[g];
+    tracked[b] = tr;
+}
+
+extern "C" int dir_fds_finalize_update_groups(const double* count, const double* mean, const double* m2, int ngroups, int C,
+                                              const int32_t* bin_ptr, int nb, int factor_mode, double momentum,
+                                              float* running_mean, float* running_var, float* num_samples_tracked, dir_stream_t stream) {
+    DIR_RETURN_IF(!count || !mean || !m2 || !bin_ptr || !running_mean || !running_var || !num_samples_tracked, DIR_EINVAL);
+    DIR_RETURN_IF(ngroups <= 0 || nb <= 0 || C <= 0 || factor_mode < 0 || factor_mode > 2, DIR_EINVAL);
+    int gy = dir_cdiv(C, DIR_TPB); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(fds_finalize_groups_tables_kernel, dim3(nb, gy), dim3(DIR_TPB), 0, dir_s(stream),
+                       count, mean, m2, C, bin_ptr, factor_mode, momentum, running_mean, running_var, num_samples_tracked);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_finalize_groups_tracked_kernel, dim3(dir_cdiv(nb, DIR_TPB)), dim3(DIR_TPB), 0, dir_s(stream),
+                       count, bin_ptr, nb, num_samples_tracked);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }

@@ -56,20 +56,23 @@ __device__ __forceinline__ uint8_t rz_clip8(int v) {
 }
 
 // The table lives in device memory, so the host entry point cannot validate it without a sync: each kernel checks the entry it works on
-// against what the launch was sized for (hmax rows of the grid, the tmp area behind the coefficient tables) and leaves an image it does not
-// fit untouched instead of writing out of bounds (dirhip.datasets.DeviceResize validates the same on the host before the launch).
-__device__ __forceinline__ bool rz_entry_fits(int H, int W, long long toff, int S, int hmax, long long tmp_bytes) {
-    return H > 0 && W > 0 && H <= hmax && toff >= 0 && toff + (long long)H * S * 3 <= tmp_bytes;
+// against what the launch was sized for (hmax rows of the grid, kmax taps per window, the source buffer's src_bytes, the tmp area behind the
+// coefficient tables) and leaves an image it does not fit untouched instead of reading or writing out of bounds (dirhip.datasets.DeviceResize validates the same on the host before the launch).
+__device__ __forceinline__ bool rz_entry_fits(int H, int W, long long soff, long long toff, int S, int hmax, int kmax, long long src_bytes, long long tmp_bytes) {
+    // reads: the image inside src, windows of at most kmax taps (the coefficient tables' row length) on both axes; writes: the tmp area
+    const long long kw = W <= S ? 3 : 2 * ((W + S - 1) / S) + 1, kh = H <= S ? 3 : 2 * ((H + S - 1) / S) + 1;      // dir_resize_ksize
+    return H > 0 && W > 0 && H <= hmax && kw <= kmax && kh <= kmax && soff >= 0 && soff + (long long)H * W * 3 <= src_bytes &&
+           toff >= 0 && toff + (long long)H * S * 3 <= tmp_bytes;
 }
 
 // horizontal: tmp[b][y][xx][c] = clip8((1 << 21) + sum_x src[b][y][xmin + x][c] * k[xx][x]); grid (ceil(Hmax * S / 256), B)
 __global__ void __launch_bounds__(DIR_TPB)
-resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ table, int S, int hmax, int kmax, long long tmp_bytes,
+resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ table, int S, int hmax, int kmax, long long src_bytes, long long tmp_bytes,
                 const int* __restrict__ bounds, const int* __restrict__ kk, uint8_t* __restrict__ tmp) {
     const int b = blockIdx.y;
     const long long soff = table[4 * b], toff = table[4 * b + 3];
     const int H = (int)table[4 * b + 1], W = (int)table[4 * b + 2];
-    if (!rz_entry_fits(H, W, toff, S, hmax, tmp_bytes)) return;     // a table entry the launch was not sized for: nothing is written for that image
+    if (!rz_entry_fits(H, W, soff, toff, S, hmax, kmax, src_bytes, tmp_bytes)) return;     // a table entry the launch was not sized for: nothing is read or written for that image
     const long long i = (long long)blockIdx.x * DIR_TPB + threadIdx.x;
     if (i >= (long long)H * S) return;
     const int y = (int)(i / S), xx = (int)(i - (long long)y * S);
@@ -90,12 +93,12 @@ resize_h_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ t
 
 // vertical: out[b][yy][xx][c] = clip8((1 << 21) + sum_y tmp[b][ymin + y][xx][c] * k[yy][y]); grid (ceil(S * S / 256), B)
 __global__ void __launch_bounds__(DIR_TPB)
-resize_v_kernel(const uint8_t* __restrict__ tmp, const long long* __restrict__ table, int S, int hmax, int kmax, long long tmp_bytes,
+resize_v_kernel(const uint8_t* __restrict__ tmp, const long long* __restrict__ table, int S, int hmax, int kmax, long long src_bytes, long long tmp_bytes,
                 const int* __restrict__ bounds, const int* __restrict__ kk, uint8_t* __restrict__ out) {
     const int b = blockIdx.y;
     const long long toff = table[4 * b + 3];
     const int H = (int)table[4 * b + 1];
-    if (!rz_entry_fits(H, (int)table[4 * b + 2], toff, S, hmax, tmp_bytes)) return;
+    if (!rz_entry_fits(H, (int)table[4 * b + 2], table[4 * b], toff, S, hmax, kmax, src_bytes, tmp_bytes)) return;
     const int i = blockIdx.x * DIR_TPB + threadIdx.x;
     if (i >= S * S) return;
     const int yy = i / S, xx = i - yy * S;
@@ -134,9 +137,9 @@ extern "C" size_t dir_resize_u8_workspace(int B, int S, int kmax, size_t tmp_byt
     return rz_coef_bytes(B, S, kmax) + dir_align_up(tmp_bytes, 256);
 }
 
-extern "C" int dir_resize_u8(const void* src, const long long* table, void* out, int B, int S, int hmax, int kmax, void* workspace,
+extern "C" int dir_resize_u8(const void* src, size_t src_bytes, const long long* table, void* out, int B, int S, int hmax, int kmax, void* workspace,
                              size_t workspace_bytes, dir_stream_t stream) {
-    DIR_RETURN_IF(!src || !table || !out || !workspace || B <= 0 || S <= 0 || hmax <= 0 || kmax <= 0, DIR_EINVAL);
+    DIR_RETURN_IF(!src || !src_bytes || !table || !out || !workspace || B <= 0 || S <= 0 || hmax <= 0 || kmax <= 0, DIR_EINVAL);
     DIR_RETURN_IF(B > 65535 || (long long)S * S >= (1ll << 31) || (long long)hmax * S >= (1ll << 31), DIR_EUNSUPPORTED);
     const size_t cb = rz_coef_bytes(B, S, kmax);
     DIR_RETURN_IF(workspace_bytes < cb + (size_t)S * 3, DIR_EWORKSPACE);       // (at least one intermediate row behind the coefficient tables)
@@ -148,9 +151,9 @@ extern "C" int dir_resize_u8(const void* src, const long long* table, void* out,
     hipLaunchKernelGGL(resize_coeffs_kernel, dim3(B, 2), dim3(DIR_TPB), 0, s, table, S, kmax, bounds, kk);
     DIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(resize_h_kernel, dim3(dir_cdiv((long long)hmax * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, static_cast<const uint8_t*>(src), table, S, hmax, kmax,
-                       tmp_bytes, bounds, kk, tmp);
+                       (long long)src_bytes, tmp_bytes, bounds, kk, tmp);
     DIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(resize_v_kernel, dim3(dir_cdiv((long long)S * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, tmp, table, S, hmax, kmax, tmp_bytes, bounds, kk,
+    hipLaunchKernelGGL(resize_v_kernel, dim3(dir_cdiv((long long)S * S, DIR_TPB), B), dim3(DIR_TPB), 0, s, tmp, table, S, hmax, kmax, (long long)src_bytes, tmp_bytes, bounds, kk,
                        static_cast<uint8_t*>(out));
     DIR_LAUNCH_CHECK();
     return DIR_OK;

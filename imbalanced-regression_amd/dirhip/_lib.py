@@ -29,6 +29,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "dir_fds_finalize_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dir_fds_finalize_update_groups": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_double,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "dir_fds_smooth_bins": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dir_fds_prepare_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "dir_fds_calibrate_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -93,7 +95,7 @@ SIGNATURES = {
     "dir_augment_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_resize_ksize": (c_int, [c_int, c_int]),
     "dir_resize_u8_workspace": (c_size_t, [c_int, c_int, c_int, c_size_t]),
-    "dir_resize_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dir_resize_u8": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dir_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dir_bn_relu_maxpool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -243,23 +243,9 @@ class _BNJoinFn(torch.autograd.Function):
 _JOIN_BWD = [True]
 
 
-def set_join_bwd(enabled):
-    """Returns the previous setting."""
-    prev = _JOIN_BWD[0]
-    _JOIN_BWD[0] = bool(enabled)
-    return prev
-
-
 # The deferred ReLU backward reads its mask as one bit per element (emitted by the forward) instead of the bf16 tensor itself.
 # Off = the tensor (tests and tools compare the two).
 _RELU_BITS = [True]
-
-
-def set_relu_bits(enabled):
-    """Returns the previous setting."""
-    prev = _RELU_BITS[0]
-    _RELU_BITS[0] = bool(enabled)
-    return prev
 
 
 def _relu_bits_for(x):

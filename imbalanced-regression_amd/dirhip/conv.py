@@ -118,29 +118,13 @@ def conv2d_igemm(x, w, stride=1, padding=0, want_stats=False, addend=None, relu_
 _WGRAD3_ALL_TAPS = [True]
 
 
-def set_wgrad3_all_taps(enabled):
-    """Returns the previous setting."""
-    prev = _WGRAD3_ALL_TAPS[0]
-    _WGRAD3_ALL_TAPS[0] = bool(enabled)
-    return prev
-
-
-# Weight gradients on a SIDE STREAM (set_wgrad_side_stream): nothing in the backward pass reads dW, so the split-K kernels need
+# Weight gradients on a SIDE STREAM (tools/variant_switches.py: set_wgrad_side_stream; off in the product): nothing in the backward pass reads dW, so the split-K kernels need
 # not sit in the chain  BatchNorm backward -> data gradient -> BatchNorm backward ...; on their own HIP stream they fill the gaps of
 # that chain (its ~5 us fold / finalize launches run on an otherwise idle chip, and every kernel has a tail). The side stream waits
 # for the producer of dY, the operands are marked as in use on it (the caching allocator must not hand their memory out while the
 # kernel runs), and the calling stream waits for the side stream once per backward pass — in an autograd end-of-pass callback, and
 # in front of every gradient-bucket collective (parallel.py) — so `.grad` is ready on the caller's stream when backward() returns.
 _WGRAD_SIDE = {"on": False, "streams": {}, "dirty": set(), "task": None}
-
-
-def set_wgrad_side_stream(enabled):
-    """Returns the previous setting. Turning it off joins whatever is still in flight."""
-    prev = _WGRAD_SIDE["on"]
-    _WGRAD_SIDE["on"] = bool(enabled)
-    if prev and not enabled:
-        wgrad_join()
-    return prev
 
 
 def wgrad_join(device=None):
@@ -183,7 +167,7 @@ def _wgrad_side_done(device, side, *operands):
         _WGRAD_SIDE["task"] = task
 
 
-# ONE split-K reduction launch per backward pass (round 5; OPT-IN: ``set_wgrad_batched_reduce(True)``): inside a backward pass a weight-gradient
+# ONE split-K reduction launch per backward pass (round 5; OPT-IN: tools/variant_switches.py: ``set_wgrad_batched_reduce(True)``): inside a backward pass a weight-gradient
 # node whose output is a gradient-bucket slot (gradsink: persistent storage that autograd adopts as ``param.grad`` by reference) runs only the
 # split-K GEMM, leaves its partials in a workspace that persists per layer, and the reduction of ALL such layers is one launch in an autograd
 # end-of-pass callback (``dir_conv_wgrad_reduce_batched``: same order per element, bit-identical): 52 launches of 5-8 us per ResNet-50 step
@@ -195,15 +179,6 @@ def _wgrad_side_done(device, side, *operands):
 # engine's collectives are live (their hooks fire per parameter, before the end of the pass).
 _WGRAD_BATCH = {"on": False, "pending": {}, "task": None, "ws": {}, "tables": {}}
 _COLLECTIVES_LIVE = [0]          # engines whose per-parameter collectives are live (parallel.DataParallelEngine): no batching while > 0
-
-
-def set_wgrad_batched_reduce(enabled):
-    """Returns the previous setting. Turning it off reduces whatever is still pending."""
-    prev = _WGRAD_BATCH["on"]
-    _WGRAD_BATCH["on"] = bool(enabled)
-    if prev and not enabled:
-        wgrad_flush()
-    return prev
 
 
 def wgrad_flush():
@@ -227,7 +202,7 @@ def wgrad_flush():
             if p is None or p.grad is None or p.grad.data_ptr() != row[3]:
                 raise RuntimeError("batched weight-gradient reduction: autograd did not adopt the gradient-bucket slot as .grad for a layer "
                                    "(the gradient it holds was copied before the end-of-pass reduction and is invalid); "
-                                   "turn conv.set_wgrad_batched_reduce off for this graph")
+                                   "do not batch this graph (tools/variant_switches.py: set_wgrad_batched_reduce)")
 
 
 def _wgrad_batch_slot(dw, from_sink, nbytes):

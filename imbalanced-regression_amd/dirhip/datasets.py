@@ -79,36 +79,6 @@ def ragged_collate(samples):
     return (flat, sizes, labels, weights) + extra
 
 
-class PinnedStager:
-    """OPTIONAL, off everywhere by default: host-to-device copies of large PAGEABLE batches through a small ring of pinned buffers (a host
-    memcpy into pinned memory, GIL released, then an asynchronous DMA; a buffer is reused once the copy out of it has finished). Built to test
-    whether the runtime's synchronous pageable copy was what held the file-fed loop back — it was not: 5.6-5.8 k img/s with the ring against
-    6.4 k without (profiles/r05_input_pipeline_end_to_end.txt; the bound is the loaders' hand-over of the ragged batches). Kept as the
-    measurement knob of ``DeviceResize(stager=)`` / ``tools/probe_input_pipeline.py e2e``. (The loader's own ``pin_memory`` would allocate a new
-    pinned block per differently sized ragged batch: tens of seconds for the pool and a fragmented host allocator.)"""
-
-    def __init__(self, nbuf=3):
-        self.bufs, self.events, self.i = [None] * nbuf, [None] * nbuf, 0
-
-    def to_device(self, t, device):
-        if t.is_cuda or t.is_pinned():
-            return t.to(device, non_blocking=True)
-        k = self.i
-        self.i = (k + 1) % len(self.bufs)
-        if self.events[k] is not None:
-            self.events[k].synchronize()
-        n = t.numel() * t.element_size()
-        if self.bufs[k] is None or self.bufs[k].numel() < n:
-            self.bufs[k] = torch.empty(int(n * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
-        p = self.bufs[k][:n].view(t.dtype).view(t.shape)
-        p.copy_(t)
-        d = p.to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        self.events[k] = ev
-        return d
-
-
 class DeviceResize:
     """GPU side of ``transforms.Resize((S, S))`` (datasets.py:41,49) for ``raw="decoded"`` batches: ``resize(flat, sizes)`` takes the
     ragged uint8 batch of ``ragged_collate`` (host or device tensors; the copy to the device happens here, non-blocking when pinned) and
@@ -118,7 +88,7 @@ class DeviceResize:
     def __init__(self, img_size, device=None, stager=None):
         self.img_size = int(img_size)
         self.device = device
-        self.stager = stager                                        # a PinnedStager: the ragged bytes travel through pinned memory
+        self.stager = stager                                        # measurement hook (tools/pinned_stager.py): an object with to_device(tensor, device); None in the product
 
     def __call__(self, flat, sizes):
         from . import _lib as L
@@ -143,7 +113,7 @@ class DeviceResize:
         table_d = table.to(dev, non_blocking=True)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         out = torch.empty((b, s, s, 3), dtype=torch.uint8, device=dev)
-        L.check(lib.dir_resize_u8(L.ptr(flat_d), L.ptr(table_d), L.ptr(out), b, s, int(h.max()), kmax, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+        L.check(lib.dir_resize_u8(L.ptr(flat_d), flat_d.numel(), L.ptr(table_d), L.ptr(out), b, s, int(h.max()), kmax, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "dir_resize_u8")
         return out
 
@@ -211,7 +181,18 @@ class DevicePrefetcher:
             yield out
 
     def close(self):
+        """Stop the producer and WAIT for it: after an early exit of the consumer (``--max_steps``, an exception in the loop) the thread may still be
+        inside ``fn(batch)`` — issuing work on the side stream, writing the HBM cache — while the next pass starts. The queue is
+        drained so that a producer blocked in ``put`` returns."""
+        import queue
         self.stop.set()
+        while self.thread.is_alive():
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)
+        self.side.synchronize()                     # whatever the producer queued on its stream has finished before anybody reuses its buffers
 
     def __del__(self):
         self.stop.set()

@@ -68,6 +68,34 @@ def merge_stats_across_ranks(count, mean, m2, group=None):
     return tot, gmean, adj
 
 
+MAX_VALUE_GROUPS = 8000     # distinct in-range label values one epoch may hold (dir_fds_scatter_stats keeps one LDS counter per group)
+
+
+def value_groups(labels, bucket_start, bucket_num, all_labels=None):
+    """Host-side row grouping of ``update_running_stats`` for NON-INTEGER labels (imdb-wiki-dir/fds.py:91-99): every distinct label
+    value v with bucket_start <= v <= bucket_num - 1 is its own group (rows ``labels == v``; the two boundary values lump the rows beyond them,
+    if the boundary value occurs at all), groups in ascending value order, group -> bin ``int(v - bucket_start)`` (float32 subtraction, truncation).
+    ``labels``: this rank's float32 labels (numpy); ``all_labels``: the labels of every rank (the group list must be the same everywhere).
+    Returns (group index per row, -1 = in no group) int32 [n], bin_ptr int32 [nb + 1], number of groups."""
+    labels = np.asarray(labels, dtype=np.float32).reshape(-1)
+    pool = labels if all_labels is None else np.asarray(all_labels, dtype=np.float32).reshape(-1)
+    lo, hi = np.float32(bucket_start), np.float32(bucket_num - 1)
+    vals = np.unique(pool[(pool >= lo) & (pool <= hi)])                  # sorted, like torch.unique; NaN compares false and is never here
+    nb = bucket_num - bucket_start
+    gid = np.full(labels.shape, -1, dtype=np.int32)
+    if vals.size:
+        pos = np.searchsorted(vals, labels)
+        hit = (pos < vals.size) & (vals[np.minimum(pos, vals.size - 1)] == labels)
+        gid[hit] = pos[hit]
+        if vals[0] == lo:
+            gid[labels <= lo] = 0                                         # fds.py:94-95
+        if vals[-1] == hi:
+            gid[labels >= hi] = vals.size - 1                             # fds.py:96-97
+    bins = (vals - lo).astype(np.int64)                                  # int(label - bucket_start): float32 subtract, truncate (fds.py:104)
+    bin_ptr = np.searchsorted(bins, np.arange(nb + 1)).astype(np.int32)
+    return gid, bin_ptr, int(vals.size)
+
+
 class FDS(nn.Module):
     # calibration constants of this variant (utils.py:97: clip [0.1, 10], columns with v1 == 0 untouched)
     CLIP = (0.1, 10.0)
@@ -204,11 +232,28 @@ class FDS(nn.Module):
         bits = int(flags.item())                      # once per epoch, like the reference's own syncs
         if bits & L.FLAG_NAN:
             raise ValueError("FDS.update_running_stats: NaN label")
+        self._bin_ptr = None
         if bits & L.FLAG_NONINTEGER:
-            raise NotImplementedError(
-                "FDS.update_running_stats: non-integer labels inside [bucket_start, bucket_num-1] trigger the "
-                "reference's sequential per-distinct-value momentum updates (SURVEY A.8); the age datasets are "
-                "integer valued and this implementation rejects anything else instead of guessing.")
+            # the reference blends once per distinct label VALUE, in ascending order. The row grouping is host logic on the [n] labels
+            # (0.8 MB at N = 191 509; the [n, C] features never leave the device): statistics per value group on the device, then the sequential
+            # blends of every bin in one launch (dir_fds_finalize_update_groups).
+            mine = labels.cpu().numpy()
+            everyone = None
+            if self._world() > 1:
+                gathered = [None] * dist.get_world_size(self.process_group)
+                dist.all_gather_object(gathered, mine, group=self.process_group)
+                everyone = np.concatenate(gathered)
+            gid, bin_ptr, ngroups = value_groups(mine, self.bucket_start, self.bucket_num, everyone)
+            if ngroups > MAX_VALUE_GROUPS:
+                raise NotImplementedError(f"FDS.update_running_stats: {ngroups} distinct non-integer label values inside the bucket range in one epoch "
+                                          f"(limit {MAX_VALUE_GROUPS}); the reference would apply as many sequential momentum updates")
+            if ngroups == 0:
+                z = torch.zeros(1, dtype=torch.float64, device=features.device)
+                self._bin_ptr = torch.zeros(nb + 1, dtype=torch.int32, device=features.device)
+                return z, torch.zeros(1, features.shape[1], dtype=torch.float64, device=features.device), \
+                    torch.zeros(1, features.shape[1], dtype=torch.float64, device=features.device)
+            self._bin_ptr = torch.from_numpy(bin_ptr).to(features.device)
+            return ops.scatter_stats(features, torch.from_numpy(gid).to(features.device), ngroups)
         return ops.scatter_stats(features, bins, nb)
 
     def update_running_stats(self, features, labels, epoch):
@@ -232,8 +277,13 @@ class FDS(nn.Module):
             mode, mom = L.FACTOR_MOMENTUM, float(self.momentum)
         else:
             mode, mom = L.FACTOR_COUNT, 0.0
-        ops.finalize_update(count, mean, m2, mode, mom, self.running_mean, self.running_var,
-                            self.num_samples_tracked)
+        bin_ptr = getattr(self, "_bin_ptr", None)
+        if bin_ptr is not None:                        # statistics per distinct label value (non-integer labels)
+            ops.finalize_update_groups(count, mean, m2, bin_ptr, mode, mom, self.running_mean, self.running_var, self.num_samples_tracked)
+            self._bin_ptr = None
+        else:
+            ops.finalize_update(count, mean, m2, mode, mom, self.running_mean, self.running_var,
+                                self.num_samples_tracked)
         self._invalidate()
 
     # ---- fds.py:115-144 -----------------------------------------------------------------------------

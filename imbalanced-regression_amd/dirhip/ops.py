@@ -101,6 +101,18 @@ def finalize_update(count, mean, m2, factor_mode, momentum, running_mean, runnin
             "dir_fds_finalize_update")
 
 
+def finalize_update_groups(count, mean, m2, bin_ptr, factor_mode, momentum, running_mean, running_var, tracked):
+    """K3 for non-integer labels: statistics per distinct-value group ([U], [U, C] f64), ``bin_ptr`` [nb + 1] int32 = first group of every bin."""
+    nb, c = running_mean.shape
+    for t, dt, nm in ((count, f64, "count"), (mean, f64, "mean"), (m2, f64, "m2"), (bin_ptr, i32, "bin_ptr"), (running_mean, f32, "running_mean"),
+                      (running_var, f32, "running_var"), (tracked, f32, "num_samples_tracked")):
+        L.require_device_tensor(t, dt, nm)
+    assert bin_ptr.numel() == nb + 1 and mean.shape == (count.numel(), c)
+    L.check(L.lib().dir_fds_finalize_update_groups(L.ptr(count), L.ptr(mean), L.ptr(m2), count.numel(), c, L.ptr(bin_ptr), nb, factor_mode,
+                                                   float(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(tracked),
+                                                   L.stream_ptr(running_mean.device)), "dir_fds_finalize_update_groups")
+
+
 # ---- K4 -------------------------------------------------------------------------------------------
 def smooth_bins(mean, var, window):
     mean = L.require_device_tensor(mean, f32, "mean table")

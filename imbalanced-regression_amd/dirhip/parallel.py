@@ -106,7 +106,9 @@ class DataParallelEngine(nn.Module):
             # the bucket collectives start from per-parameter hooks, i.e. before the end of the backward pass: every weight gradient must be
             # complete when its node returns — the one-launch-per-pass split-K reduction of conv.py is for the one-process loop
             from . import conv as _conv
-            _conv.set_wgrad_batched_reduce(False)
+            if _conv._WGRAD_BATCH["on"]:
+                _conv._WGRAD_BATCH["on"] = False
+                _conv.wgrad_flush()
             _conv._COLLECTIVES_LIVE[0] += 1                 # guards the point of use too: turning the switch back on later changes nothing
             import weakref
             weakref.finalize(self, _release_collectives_guard)
@@ -237,7 +239,7 @@ class DataParallelEngine(nn.Module):
     def _launch(self, b):
         if b.flat.is_cuda:
             from . import conv as _conv
-            _conv.wgrad_join(b.flat.device)                  # weight gradients written on the side stream (conv.set_wgrad_side_stream)
+            _conv.wgrad_join(b.flat.device)                  # weight gradients written on the side stream (tools/variant_switches.py; off in the product)
         if self.measure_comm and b.flat.is_cuda:
             b.ev0 = torch.cuda.Event(enable_timing=True)
             b.ev0.record()

@@ -114,7 +114,7 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         y = torch.empty((n, c, ho, wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
         # x at the argmax, for the backward's sum g * x (pooled size: 1/4 of x); None = the older pair (gather reduction, per-pixel apply)
-        xmax = torch.empty_like(y) if (_STEM_TAIL_XMAX and want_xmax) else None   # (no backward, e.g. the no-grad epoch-tail forward: not written at all)
+        xmax = torch.empty_like(y) if (_STEM_TAIL_XMAX[0] and want_xmax) else None   # (no backward, e.g. the no-grad epoch-tail forward: not written at all)
         L.check(L.lib().dir_bn_relu_maxpool_fwd_xmax(L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(idx), L.ptr(xmax), n, h, w, c, stream),
                 "dir_bn_relu_maxpool_fwd_xmax")
         ctx.save_for_backward(x, gamma, mean, rstd, idx, xmax)
@@ -139,15 +139,9 @@ class _BnReluMaxPoolFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-_STEM_TAIL_XMAX = True
-
-
-def set_stem_tail_xmax(on):
-    """Python-level switch for tests / A/B runs: keep the forward's x-at-argmax for the stem tail's backward (default) or not. Returns
-    the previous setting. (The C-ABI has no mode switch: the backward's form follows from the xmax argument being given or NULL.)"""
-    global _STEM_TAIL_XMAX
-    prev, _STEM_TAIL_XMAX = _STEM_TAIL_XMAX, bool(on)
-    return prev
+# keep the forward's x-at-argmax for the stem tail's backward (the product's form) or recompute it (the C-ABI has no mode switch: the backward's
+# form follows from the xmax argument being given or NULL). A constant of the product; tools/variant_switches.py flips it for A/B runs and tests.
+_STEM_TAIL_XMAX = [True]
 
 
 def bn_relu_maxpool(x, bn, pool, partial=None):

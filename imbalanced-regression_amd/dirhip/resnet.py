@@ -32,29 +32,15 @@ print = logging.info
 
 # The fused wiring of a bottleneck block (shared block-input gradient accumulation inside conv1's data-gradient kernel,
 # ReLU backward of relu(bn3 + shortcut) deferred into the consumer, projection pair, two-BatchNorm join) is ONE graph for
-# both activation dtypes. ``set_graph_fusion(False)`` builds the plain composition of the very same kernels instead
+# both activation dtypes. The graph-fusion constant below set to False (tools/variant_switches.py: tests only) builds the plain composition of the very same kernels instead
 # (conv -> BatchNorm(+residual)(+ReLU) nodes, autograd's own gradient accumulation): the tests use it as the oracle for
 # the fusion wiring — both graphs must produce the same forward bit for bit and the same gradients.
 _FUSED_GRAPH = [True]
 
 
-def set_graph_fusion(enabled):
-    """Returns the previous setting."""
-    prev = _FUSED_GRAPH[0]
-    _FUSED_GRAPH[0] = bool(enabled)
-    return prev
-
-
 # BatchNorm backward: form the per-channel sums inside the data-gradient kernel that produces the BatchNorm's `dout`
 # (bn.BwdLink) instead of in a reduction pass of their own. Off = the plain three-pass dir_bn_bwd (tests compare the two).
 _FUSE_BN_BWD = [True]
-
-
-def set_bn_bwd_fusion(enabled):
-    """Returns the previous setting."""
-    prev = _FUSE_BN_BWD[0]
-    _FUSE_BN_BWD[0] = bool(enabled)
-    return prev
 
 
 def _fusable(x):

@@ -94,7 +94,10 @@ def build_parser(dataset_default='imdb_wiki'):
                    'GPU as well (dir_resize_u8: Pillow\'s bilinear arithmetic bit for bit, on the ragged uint8 batch), then dir_augment_u8')
     p.add_argument('--gpu_cache', action='store_true', help='image files only, with --gpu_augment / --gpu_resize: keep the resized uint8 training images in HBM '
                    '(datasets.DeviceImageCache: 28.8 GB for IMDB-WIKI at 224); the FDS feature pass of the same epoch and every later epoch gather them '
-                   'there and draw a fresh augmentation on the GPU: no JPEG decode after the first training pass')
+                   'there and draw a fresh augmentation on the GPU: no JPEG decode after the first training pass. NOTE (more than one rank): the partition '
+                   'of the training set over the ranks is then FIXED for the whole run (every rank caches its own shard; batches never mix samples of '
+                   'different shards and a rank\'s BatchNorm statistics always see the same subset) — unlike the default path, which redraws the partition '
+                   'every epoch like a DistributedSampler; every rank allocates the full-size cache')
     p.add_argument('--overwrite', action='store_true', help='delete an existing run folder of the same name (the reference asks on '
                    'the terminal; without a terminal nothing is deleted unless this flag is given)')
     p.set_defaults(augment=True)
@@ -339,7 +342,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
         aug_dtype = torch.bfloat16 if args.amp == 'bf16' else torch.float32
         aug_train = datasets.DeviceAugment(args.img_size, train=True, dtype=aug_dtype) if raw else None
         aug_eval = datasets.DeviceAugment(args.img_size, train=False, dtype=aug_dtype) if raw else None
-        dev_resize = datasets.DeviceResize(args.img_size, device) if args.gpu_resize else None     # (PinnedStager measured slower: off, as in bench.py)
+        dev_resize = datasets.DeviceResize(args.img_size, device) if args.gpu_resize else None     # (a pinned staging ring measured slower: tools/pinned_stager.py)
         collate = datasets.ragged_collate if args.gpu_resize else None
 
         # --gpu_resize hands over RAGGED file-size batches (~4x the bytes, a different size every time): pageable, like the configuration

@@ -103,6 +103,15 @@ int dir_fds_finalize_update(const double* count, const double* mean, const doubl
                             int factor_mode, double momentum,
                             float* running_mean, float* running_var, float* num_samples_tracked,
                             dir_stream_t stream);
+/* K3 for NON-INTEGER labels (ABI 3).  imdb-wiki-dir/fds.py:91-111 loops over torch.unique(labels): every distinct label VALUE
+ * inside [bucket_start, bucket_num - 1] is its own row group and triggers its own blend of bin int(value - bucket_start), in ascending value
+ * order (the boundary values lump the out-of-range rows, fds.py:94-97).  count / mean / m2 hold the statistics per value GROUP
+ * (dir_fds_scatter_stats with the group index as the "bin": [ngroups], [ngroups, C]; groups sorted by value), bin_ptr [nb + 1] (device) the
+ * first group of every bin.  For every bin the blends of dir_fds_finalize_update are applied one after the other, num_samples_tracked
+ * advancing group by group (it enters the count-based factor of mode 2). */
+int dir_fds_finalize_update_groups(const double* count, const double* mean, const double* m2, int ngroups, int C,
+                                   const int32_t* bin_ptr, int nb, int factor_mode, double momentum,
+                                   float* running_mean, float* running_var, float* num_samples_tracked, dir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  smoothing across the bin axis.  Replaces the two F.pad(reflect) + F.conv1d calls of
@@ -450,8 +459,8 @@ int dir_augment_u8(const void* img, const int* params, void* out, int dtype, int
  *   chosen by the host).  Three launches, no host sync. */
 int    dir_resize_ksize(int in_size, int out_size);
 size_t dir_resize_u8_workspace(int B, int S, int kmax, size_t tmp_bytes);
-int    dir_resize_u8(const void* src, const long long* table, void* out, int B, int S, int hmax, int kmax, void* workspace,
-                     size_t workspace_bytes, dir_stream_t stream);
+int    dir_resize_u8(const void* src, size_t src_bytes, const long long* table, void* out, int B, int S, int hmax, int kmax, void* workspace,
+                     size_t workspace_bytes, dir_stream_t stream);    /* (ABI 3: src_bytes — table entries are checked against the source buffer too) */
 
 
 

@@ -13,10 +13,27 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "imbalanced-regression_amd")
-for p in (ROOT, PKG):
+for p in (ROOT, PKG, os.path.join(ROOT, "tools")):        # (tools/: variant_switches.py, the tests' A/B switches of the product's kernel-path constants)
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+_RECORDS = [None]
+
+
+def records_dir():
+    """Where the -m gpu tests put the measurement records some of them produce (achieved parity errors, communication reports, CLI logs):
+    $DIR_TEST_RECORDS when set (e.g. `DIR_TEST_RECORDS=gpurun_out python -m pytest -m gpu ...` carries them back from the GPU box), otherwise a
+    temporary directory — a plain test run leaves no files in the tree (VERDICT r5 hygiene)."""
+    if _RECORDS[0] is None:
+        d = os.environ.get("DIR_TEST_RECORDS")
+        if d:
+            d = d if os.path.isabs(d) else os.path.join(ROOT, d)
+            os.makedirs(d, exist_ok=True)
+        else:
+            import tempfile
+            d = tempfile.mkdtemp(prefix="dir_test_records_")
+        _RECORDS[0] = d
+    return _RECORDS[0]
 
 
 def pytest_configure(config):

@@ -4,6 +4,8 @@ whole dirhip ResNet-50 (fp32 mode) vs the reference's CPU forward golden."""
 import numpy as np
 import pytest
 import torch
+
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -208,7 +210,7 @@ def test_bn_join_backward_one_pass_pair_is_bit_identical_to_two_backwards(shape,
     dy = torch.randn(shape, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
     got = {}
     for on in (True, False):
-        prev = B.set_join_bwd(on)
+        prev = VS.set_join_bwd(on)
         try:
             bn, bn_r = nn.BatchNorm2d(c).cuda(), nn.BatchNorm2d(c).cuda()
             gg = torch.Generator(device="cuda").manual_seed(7)
@@ -222,7 +224,7 @@ def test_bn_join_backward_one_pass_pair_is_bit_identical_to_two_backwards(shape,
             y.backward(torch.where(y > 0, dy, torch.zeros_like(dy)))
             got[on] = [t.detach().clone() for t in (x.grad, r.grad, bn.weight.grad, bn.bias.grad, bn_r.weight.grad, bn_r.bias.grad)]
         finally:
-            B.set_join_bwd(prev)
+            VS.set_join_bwd(prev)
     for a, b, name in zip(got[True], got[False], ("dx", "dr", "dgamma", "dbeta", "dgamma_r", "dbeta_r")):
         assert torch.equal(a, b), name
 
@@ -270,7 +272,7 @@ def test_stem_tail_backward_modes_bit_identical():
         dy = None
         got = {}
         for use_xmax in (False, True):
-            prev = P.set_stem_tail_xmax(use_xmax)
+            prev = VS.set_stem_tail_xmax(use_xmax)
             try:
                 bn = nn.BatchNorm2d(c).cuda()
                 with torch.no_grad():
@@ -283,6 +285,6 @@ def test_stem_tail_backward_modes_bit_identical():
                 y.backward(dy)
                 got[use_xmax] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
             finally:
-                P.set_stem_tail_xmax(prev)
+                VS.set_stem_tail_xmax(prev)
         for a, b, name in zip(got[True], got[False], ("y", "dx", "dgamma", "dbeta")):
             assert torch.equal(a, b), (shape, name)

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
+
 from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -244,8 +246,8 @@ def test_in_situ_sums_vs_float64_and_vs_three_pass(monkeypatch):
     assert len(records) == 43, len(records)
     import json
     import os
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(records, open("gpurun_out/bn_bwd_fusion_in_situ.json", "w"), indent=1)
+    from conftest import records_dir
+    json.dump(records, open(os.path.join(records_dir(), "bn_bwd_fusion_in_situ.json"), "w"), indent=1)
     worst = {k: max(r[k] for r in records) for k in ("e_sum", "dgamma_fused", "dgamma_3pass", "dbeta_fused", "dbeta_3pass", "dx_rel_l2", "dx_diff_frac")}
     # float32 accumulation of <= 128 terms per tile, float64 across tiles: 2e-6 of the sum of magnitudes
     assert worst["e_sum"] <= 2e-6, worst
@@ -280,12 +282,12 @@ def test_whole_model_fused_vs_three_pass_bn_backward():
     res = {}
     counts = {}
     for fused in (True, False):
-        prev = R.set_bn_bwd_fusion(fused)
+        prev = VS.set_bn_bwd_fusion(fused)
         try:
             counts[fused] = _kernel_counts(step)
             out = step()
         finally:
-            R.set_bn_bwd_fusion(prev)
+            VS.set_bn_bwd_fusion(prev)
         res[fused] = (out, {n: p.grad.detach().double().clone() for n, p in model.named_parameters()})
 
     def n_partial(c):                               # (reduction passes of single BatchNorms, of the four joins' pairs)
@@ -307,6 +309,6 @@ def test_whole_model_fused_vs_three_pass_bn_backward():
     assert rels["layer4.2.bn2.weight"] <= 1e-4 and rels["layer4.2.bn2.bias"] <= 1e-4, (rels["layer4.2.bn2.weight"], rels["layer4.2.bn2.bias"])
     import json
     import os
-    os.makedirs("gpurun_out", exist_ok=True)
+    from conftest import records_dir
     json.dump({"by_stage_max_rel_l2": by_stage, "median": float(np.median(list(rels.values()))), "worst": worst},
-              open("gpurun_out/bn_bwd_fusion_whole_model.json", "w"), indent=1)
+              open(os.path.join(records_dir(), "bn_bwd_fusion_whole_model.json"), "w"), indent=1)

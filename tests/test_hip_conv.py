@@ -4,6 +4,8 @@ BatchNorm partial statistics."""
 import numpy as np
 import pytest
 import torch
+
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
 import torch.nn.functional as F
 
 from conftest import assert_close
@@ -176,12 +178,12 @@ def test_bottleneck_fused_shortcut_gradient_matches_unfused():
         out.backward(dy)
         return out.detach().float(), x.grad.float(), [p.grad.clone() for p in blk.parameters()]
 
-    prev = R.set_bn_bwd_fusion(False)      # (the BatchNorm sums stay in their own kernel on both sides: this test is about the edges)
+    prev = VS.set_bn_bwd_fusion(False)      # (the BatchNorm sums stay in their own kernel on both sides: this test is about the edges)
     try:
         o1, gx1, gp1 = run(True)
         o2, gx2, gp2 = run(False)
     finally:
-        R.set_bn_bwd_fusion(prev)
+        VS.set_bn_bwd_fusion(prev)
     assert torch.equal(o1, o2)
     assert_close(gx1.cpu().numpy(), gx2.cpu().numpy(), rtol=1e-2, atol_scale=4e-3, msg="dx")
     for a, b in zip(gp1, gp2):
@@ -309,12 +311,12 @@ def test_deferred_relu_backward_is_bit_identical():
         out.backward(dy)
         return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]
 
-    prev = R.set_bn_bwd_fusion(False)      # bn3's sums would otherwise move into conv1's epilogue only when the ReLU is deferred
+    prev = VS.set_bn_bwd_fusion(False)      # bn3's sums would otherwise move into conv1's epilogue only when the ReLU is deferred
     try:
         o1, gx1, gp1 = run(True)
         o2, gx2, gp2 = run(False)
     finally:
-        R.set_bn_bwd_fusion(prev)
+        VS.set_bn_bwd_fusion(prev)
     assert torch.equal(o1, o2)
     assert torch.equal(gx1, gx2)
     for a, b in zip(gp1, gp2):
@@ -340,7 +342,7 @@ def test_relu_bit_mask_is_bit_identical_to_the_tensor_mask():
     dy = torch.randn(6, 512, 14, 14, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
     def run(bits):
-        prev = B.set_relu_bits(bits)
+        prev = VS.set_relu_bits(bits)
         try:
             for p in params:
                 p.grad = None
@@ -356,7 +358,7 @@ def test_relu_bit_mask_is_bit_identical_to_the_tensor_mask():
                 seen.append(hasattr(y, "_dir_relu_bits"))
             y.backward(dy)
         finally:
-            B.set_relu_bits(prev)
+            VS.set_relu_bits(prev)
         return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params], seen
 
     y1, gx1, gp1, seen1 = run(True)
@@ -460,7 +462,7 @@ def test_batched_weight_gradient_reduction_is_bit_identical_and_one_launch():
     from dirhip.train_loop import resolve_loss
 
     def grads(batched):
-        prev = C.set_wgrad_batched_reduce(batched)
+        prev = VS.set_wgrad_batched_reduce(batched)
         try:
             torch.manual_seed(0)
             model = resnet50(fds=True, bucket_num=100, bucket_start=0, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).cuda()
@@ -484,7 +486,7 @@ def test_batched_weight_gradient_reduction_is_bit_identical_and_one_launch():
                 names = [(e.key, e.count) for e in prof.key_averages()]
             return out, names
         finally:
-            C.set_wgrad_batched_reduce(prev)
+            VS.set_wgrad_batched_reduce(prev)
     a, names_a = grads(False)
     b, names_b = grads(True)
     for ga, gb in zip(a, b):

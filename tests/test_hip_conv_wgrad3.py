@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
+
 from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -63,13 +65,13 @@ def test_all_taps_wgrad_vs_per_tap_kernel_and_float64(n, cin, cout, hw):
     # a transpose-detecting pattern on top of the noise: channel- and position-dependent ramps
     x = _cl((x.float() + torch.arange(cin, device="cuda").view(1, -1, 1, 1) * 0.01
              + torch.arange(hw, device="cuda").view(1, 1, -1, 1) * 0.02 - torch.arange(hw, device="cuda").view(1, 1, 1, -1) * 0.03).to(torch.bfloat16))
-    prev = C.set_wgrad3_all_taps(True)
+    prev = VS.set_wgrad3_all_taps(True)
     try:
         dw = C.conv2d_wgrad(dy, x, 3, 1, 1)
-        C.set_wgrad3_all_taps(False)
+        VS.set_wgrad3_all_taps(False)
         dw_tap = C.conv2d_wgrad(dy, x, 3, 1, 1)
     finally:
-        C.set_wgrad3_all_taps(prev)
+        VS.set_wgrad3_all_taps(prev)
     assert dw.shape == (cout, cin, 3, 3) and dw.is_contiguous(memory_format=torch.channels_last)
     ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=1, padding=1)
     scale = float(ref.abs().max())
@@ -111,11 +113,11 @@ def test_all_taps_wgrad_full_size_vs_per_tap_and_linearity(c, hw):
     ab = _cl((a.float() + b.float()).to(torch.bfloat16))
     exact = torch.equal(ab.float(), a.float() + b.float())
     dwa, dwb, dwab = C.conv2d_wgrad(a, x, 3, 1, 1), C.conv2d_wgrad(b, x, 3, 1, 1), C.conv2d_wgrad(ab, x, 3, 1, 1)
-    prev = C.set_wgrad3_all_taps(False)
+    prev = VS.set_wgrad3_all_taps(False)
     try:
         dwa_tap = C.conv2d_wgrad(a, x, 3, 1, 1)
     finally:
-        C.set_wgrad3_all_taps(prev)
+        VS.set_wgrad3_all_taps(prev)
     scale = float(dwa.abs().max())
     assert float((dwa - dwa_tap).abs().max()) <= 2e-5 * scale
     if exact:

@@ -23,8 +23,8 @@ def _cli(args, log):
     cmd = [sys.executable, os.path.join(PKG, "imdb-wiki-dir", "train.py")] + args
     p = subprocess.run(cmd, cwd=os.path.join(PKG, "imdb-wiki-dir"), capture_output=True, text=True, timeout=900)
     out = p.stdout + p.stderr
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", log), "w") as f:
+    from conftest import records_dir
+    with open(os.path.join(records_dir(), log), "w") as f:
         f.write(" ".join(cmd) + "\n" + out)
     assert p.returncode == 0, out[-3000:]
     return out
@@ -326,8 +326,8 @@ def test_two_rank_train_steps_equal_single_process_emulation(tmp_path):
         # bucket — nothing per parameter)
         assert ops.get("aten::copy_", 0) <= 8 + 2 * len(rep["buckets_MB"]) and ops.get("aten::mul", 0) <= 2 and ops.get("aten::mul_", 0) == 0, rep
         assert "exposed_comm_ms_last_step" in rep
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
+    from conftest import records_dir
+    out = records_dir()
     with open(os.path.join(out, "two_rank_comm_report.json"), "w") as f:
         json.dump(json.load(open(tmp_path / "comm0.json")), f, indent=1)
     # single-process emulation: replicas = two BN-buffer sets over shared parameters
@@ -399,7 +399,7 @@ def test_bench_multi_rank_control_flow_two_processes_one_gpu(tmp_path):
     assert rf["launches_per_step"] >= 100 and "step_breakdown_in_situ" in r and "peaks" in r
     cb = r["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["batch"] == 8, cb
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
+    from conftest import records_dir
+    out = records_dir()
     with open(os.path.join(out, "bench_two_ranks_one_gpu.json"), "w") as f:
         json.dump(r, f, indent=1)

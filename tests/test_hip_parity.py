@@ -79,7 +79,7 @@ def test_label_flags_noninteger_and_nan():
     assert not int(f.item()) & 12
 
 
-@pytest.mark.parametrize("name", ["imdb", "agedb", "absent", "nomomentum"])
+@pytest.mark.parametrize("name", ["imdb", "agedb", "absent", "nomomentum", "frac", "fracnomom"])   # (frac*: non-integer labels, SURVEY A.8: gen_golden_r6.py)
 def test_fds_state_machine_vs_reference_golden(golden, name):
     """Every buffer after every call of the epoch loop vs the reference's own outputs (1e-5 relative),
     and smooth() forward/backward vs the reference with its tables injected."""

@@ -115,6 +115,24 @@ def _worker(rank, port, tmp):
     out["allreduce_calls_in_plain_step"] = sum(1 for n in names0 if n.startswith("host:c10d::allreduce_"))
     out["rccl_device_kernels_in_one_step"] = len(dev_k(names1))      # (informational: a one-rank communicator may not need a kernel)
     out["rccl_device_kernel_names"] = sorted(set(dev_k(names1)))[:4]
+    # ---- non-integer labels through the N > 1 branch: labels all-gathered for the common value-group list, per-group statistics merged
+    from dirhip.fds import FDS
+    rng = np.random.default_rng(3)
+    kw = dict(feature_dim=64, bucket_num=30, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=None)
+    Fa, Fb = FDS(**kw).cuda(), FDS(**kw).cuda()
+    Fb.force_collectives = True
+    for ep in range(3):
+        lab = (np.round(rng.normal(15, 8, 400) * 2) / 2).astype(np.float32)
+        lab[:4] = [3.0, 29.0, 2.5, 30.5]
+        feats = (np.abs(rng.normal(0, 1, (400, 64))) * 0.5 + 0.02 * lab[:, None]).astype(np.float32)
+        for Fx in (Fa, Fb):
+            Fx.update_last_epoch_stats(ep)
+            Fx.update_running_stats(torch.tensor(feats).cuda(), torch.tensor(lab).cuda(), ep)
+    worst = 0.0
+    for (k, a), (_, bb) in zip(Fa.named_buffers(), Fb.named_buffers()):
+        worst = max(worst, float((a.double() - bb.double()).abs().max() / max(float(a.double().abs().max()), 1e-30)))
+    out["frac_labels_forced_vs_plain_max_rel"] = worst
+    out["frac_labels_counts_equal"] = bool(torch.equal(Fa.num_samples_tracked, Fb.num_samples_tracked))
     with open(os.path.join(tmp, "rccl.json"), "w") as f:
         json.dump(out, f, indent=1)
     dist.destroy_process_group()
@@ -130,13 +148,14 @@ def test_rccl_world1_every_collective_of_the_design_and_the_engine_branch(tmp_pa
             p.kill()                                               # (our own child, by handle)
         pytest.fail("the RCCL world-size-1 worker did not finish within 600 s")
     out = json.load(open(tmp_path / "rccl.json"))
-    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(prof, exist_ok=True)
+    from conftest import records_dir
+    prof = records_dir()
     json.dump(out, open(os.path.join(prof, "rccl_world1.json"), "w"), indent=1)
     assert out["backend"] == "nccl"
     assert out["avg_f32_identity"] and out["sum_f64_identity"] and out["max_i32_identity"] and out["broadcast_identity"], out
     assert out["params_bit_identical"], "engine over RCCL (1 rank) != engine without collectives"
     assert out["fds_counts_equal"] and out["fds_buffers_max_rel"] <= 1e-6, out         # Chan merge of ONE triple: n*mean/n round trip in float64
+    assert out["frac_labels_counts_equal"] and out["frac_labels_forced_vs_plain_max_rel"] <= 1e-6, out
     rep = out["report_forced"]
     assert rep["backend"] == "nccl" and rep["reduce_op"].startswith("avg") and rep["grad_copies"] == 0 and rep["bucket_scale_kernels"] == 0, rep
     assert rep["grad_is_bucket_view"] and rep["n_buckets"] >= 3

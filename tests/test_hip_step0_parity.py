@@ -16,7 +16,7 @@ calibration (epoch 2, tables populated by two update rounds) + weighted_l1_loss 
     projection-pair edge, without the mask-flip noise of a cross-precision comparison.
   * bf16 product path vs the reference: loss / encoding / predictions at the measured bf16 tolerance (the random-init
     network amplifies a perturbation ~20x through its depth: 1e-7 -> 1.4e-5 in float32, 4e-3 -> 1e-1 in bf16).
-The achieved errors are written to gpurun_out/parity_step0.json (quoted in DESIGN.md).
+The achieved errors are written to <records>/parity_step0.json (conftest.records_dir: $DIR_TEST_RECORDS, else a temporary directory).
 """
 import json
 import os
@@ -24,6 +24,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
 
 from conftest import ROOT, assert_close
 
@@ -33,8 +35,8 @@ _RESULTS = {}
 
 
 def _dump():
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
+    from conftest import records_dir
+    out = records_dir()
     with open(os.path.join(out, "parity_step0.json"), "w") as f:
         json.dump(_RESULTS, f, indent=1)
 
@@ -76,14 +78,14 @@ def _run_step(g, amp, fused=True):
     for ep, (f, l) in enumerate(rounds):
         model.FDS.update_last_epoch_stats(ep)
         model.FDS.update_running_stats(f.cuda(), l.cuda(), ep)
-    prev = R.set_graph_fusion(fused)
+    prev = VS.set_graph_fusion(fused)
     try:
         pred, enc = eng(x.cuda(), y.cuda(), cfg["epoch"])
         loss = weighted_l1_loss(pred, y.cuda(), w.cuda())
         eng.zero_grad()
         loss.backward()
     finally:
-        R.set_graph_fusion(prev)
+        VS.set_graph_fusion(prev)
     torch.cuda.synchronize()
     return cfg, model, loss, pred, enc, tail
 
@@ -212,20 +214,20 @@ def _run_chain(blocks, x0, dy, dtype, fused):
                 m.reset_running_stats()
         b.zero_grad()
     x = x0.to(dtype).requires_grad_(True)
-    prev = R.set_graph_fusion(fused)
+    prev = VS.set_graph_fusion(fused)
     # the BatchNorm reductions stay in their own kernel on both sides: with them inside the data-gradient epilogues (the product
     # default) the sums are formed in another order, and this random-init network amplifies a 1e-6 difference per BatchNorm to
     # 1e-3...1e-2 over a chain — that fusion has its own in-situ float64 check (tests/test_hip_bn_bwd_fusion.py); here the edges
     # of the graph are compared bit for bit
-    prev_bn = R.set_bn_bwd_fusion(False)
+    prev_bn = VS.set_bn_bwd_fusion(False)
     try:
         y = x
         for b in blocks:
             y = b(y)
         y.backward(dy.to(y.dtype))
     finally:
-        R.set_graph_fusion(prev)
-        R.set_bn_bwd_fusion(prev_bn)
+        VS.set_graph_fusion(prev)
+        VS.set_bn_bwd_fusion(prev_bn)
     grads = {f"{i}.{n}": p.grad.detach().double().clone() for i, b in enumerate(blocks) for n, p in b.named_parameters()}
     return y.detach().double(), x.grad.detach().double(), grads
 

@@ -71,7 +71,7 @@ def test_calibrate_bit_exact(golden):
         assert np.array_equal(y, g[f"ref_y_{i}"]), i
 
 
-@pytest.mark.parametrize("name", ["imdb", "agedb", "absent", "nomomentum"])
+@pytest.mark.parametrize("name", ["imdb", "agedb", "absent", "nomomentum", "frac", "fracnomom"])    # (frac*: non-integer labels; gen_golden_r6.py)
 def test_fds_state_machine(golden, name):
     g = golden(f"fds_trace_{name}.npz")
     kw = json.loads(str(g["kw"]))

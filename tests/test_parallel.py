@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import torch
+
+import variant_switches as VS  # tools/variant_switches.py: the product package has no setters (conftest puts tools/ on the path)
 import torch.nn as nn
 
 
@@ -120,13 +122,13 @@ def _ffbb_worker(rank, world, port, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dirhip import conv as C
     from dirhip.parallel import DataParallelEngine
-    C.set_wgrad_batched_reduce(True)
+    VS.set_wgrad_batched_reduce(True)
     eng = DataParallelEngine(_net(), bucket_mb=0.001)
     # live collectives start from per-parameter hooks, before the end of the backward pass: the one-launch-per-pass weight-gradient
     # reduction (conv.set_wgrad_batched_reduce) must be off under them
     assert C._WGRAD_BATCH["on"] is False
     # ... and stays ineffective if somebody turns it back on while the engine lives (guarded at the point of use)
-    C.set_wgrad_batched_reduce(True)
+    VS.set_wgrad_batched_reduce(True)
     assert C._COLLECTIVES_LIVE[0] > 0 and C._wgrad_batch_slot(torch.empty(4), True, 16) is None
     eng.train()
     d = np.load(os.path.join(tmp, "data.npz"))

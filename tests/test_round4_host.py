@@ -69,7 +69,7 @@ def test_device_resize_refuses_cpu_target():
     lib = L.lib()
     assert lib.dir_resize_ksize(320, 224) == 5 and lib.dir_resize_ksize(100, 224) == 3 and lib.dir_resize_ksize(2048, 224) == 21 and lib.dir_resize_ksize(0, 224) == 0
     assert lib.dir_resize_u8_workspace(256, 224, 5, 1000) > 256 * 2 * 224 * 7 * 4 and lib.dir_resize_u8_workspace(0, 224, 5, 0) == 0
-    assert lib.dir_resize_u8(None, None, None, 1, 224, 10, 3, None, 0, None) == -1
+    assert lib.dir_resize_u8(None, 0, None, None, 1, 224, 10, 3, None, 0, None) == -1
     assert lib.dir_sgd_step(None, 1, 0.1, 0.9, 0.0, 0.0, 0, 0, None) == -1
 
 

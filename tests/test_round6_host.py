@@ -55,3 +55,38 @@ def test_bench_extras_live_outside_bench_py():
     for name in ("def conv_layer_probe", "def input_pipeline_probe", "def library_baseline", "def float32_mode_probe"):
         assert name not in src
         assert name in open(os.path.join(ROOT, "tools", "bench_extras.py")).read()
+
+
+def test_value_groups_equal_the_reference_row_groups():
+    """SURVEY A.8 host logic: dirhip.fds.value_groups (the row grouping of update_running_stats for non-integer labels) against the oracle's restatement
+    of the reference's torch.unique loop (oracle/fds_oracle.py:_row_groups, fds.py:91-99), boundary values present / absent, multi-rank label pools."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
+    from dirhip.fds import value_groups
+    from oracle.fds_oracle import _row_groups
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        start, num = int(rng.integers(0, 4)), int(rng.integers(8, 30))
+        step = float(rng.choice([0.5, 0.25, 0.125, 1.0]))
+        labels = (np.round(rng.normal((start + num) / 2, num / 3, 300) / step) * step).astype(np.float32)
+        if trial % 3 == 0:
+            labels = labels[(labels != start) & (labels != num - 1)]              # boundary values absent: nothing lumps the out-of-range rows
+        elif trial % 3 == 1:
+            labels[:2] = start; labels[2:4] = num - 1
+        gid, bin_ptr, ng = value_groups(labels, start, num)
+        exp_gid = np.full(labels.shape, -1, np.int32)
+        exp_bins = []
+        for g, (v, rows) in enumerate(_row_groups(labels, start, num)):
+            exp_gid[rows] = g
+            exp_bins.append(int(np.float32(v) - np.float32(start)))
+        assert ng == len(exp_bins) and np.array_equal(gid, exp_gid), trial
+        nb = num - start
+        assert bin_ptr.shape == (nb + 1,) and bin_ptr[0] == 0 and bin_ptr[-1] == ng
+        for g, b in enumerate(exp_bins):
+            assert bin_ptr[b] <= g < bin_ptr[b + 1], (trial, g, b)
+        # a second "rank" contributes values this rank does not hold: the group list is the union's, this rank's rows index into it
+        other = (np.round(rng.normal((start + num) / 2, num / 3, 100) / step) * step).astype(np.float32)
+        both = np.concatenate([labels, other])
+        gid2, bin_ptr2, ng2 = value_groups(labels, start, num, all_labels=both)
+        gid_all, _, ng_all = value_groups(both, start, num)
+        assert ng2 == ng_all and np.array_equal(gid2, gid_all[:labels.size])

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
 import bench  # noqa: E402
+import variant_switches as VS  # noqa: E402
 from dirhip import _lib as L  # noqa: E402
 from dirhip import bn as B  # noqa: E402
 from dirhip import conv as C  # noqa: E402
@@ -26,8 +27,8 @@ def main():
     from dirhip import pool as P
     # Python-level wiring switches only: the C-ABI has no process-wide kernel switches any more (kernel variants are per-launch arguments;
     # to A/B two builds of a kernel use tools/ab_two_libs.py)
-    setter = {"joinbwd": B.set_join_bwd, "wgrad3": C.set_wgrad3_all_taps, "bnfuse": R.set_bn_bwd_fusion, "relubits": B.set_relu_bits,
-              "wgradside": C.set_wgrad_side_stream, "stemtail": P.set_stem_tail_xmax, "wgradbatch": C.set_wgrad_batched_reduce}[which]
+    setter = {"joinbwd": VS.set_join_bwd, "wgrad3": VS.set_wgrad3_all_taps, "bnfuse": VS.set_bn_bwd_fusion, "relubits": VS.set_relu_bits,
+              "wgradside": VS.set_wgrad_side_stream, "stemtail": VS.set_stem_tail_xmax, "wgradbatch": VS.set_wgrad_batched_reduce}[which]
 
     class A:
         batch, epoch_len, gpus = 256, 8, 1

@@ -268,7 +268,8 @@ def end_to_end_from_files(device, df, data_dir, workers, batch, synthetic_img_s,
     dir_resize_u8, dir_augment_u8 on a side stream) and its resized bytes are stored in the HBM cache; CACHED — what every pass after a
     sample's first one costs: gather from datasets.DeviceImageCache + a fresh dir_augment_u8 draw, no loader."""
     from torch.utils.data import DataLoader, Dataset, RandomSampler
-    from dirhip.datasets import IMDBWIKI, DeviceAugment, DeviceImageCache, DevicePrefetcher, DeviceResize, PinnedStager, ragged_collate
+    from dirhip.datasets import IMDBWIKI, DeviceAugment, DeviceImageCache, DevicePrefetcher, DeviceResize, ragged_collate
+    from pinned_stager import PinnedStager
     from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
 
     class A:

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
 import bench  # noqa: E402
+import variant_switches as VS  # noqa: E402
 from dirhip import conv as C  # noqa: E402
 from dirhip.train_loop import resolve_loss, train_step  # noqa: E402
 
@@ -25,7 +26,7 @@ def main():
     model, engine, optimizer, batches = bench.build(A, device, 0)
     loss_fn = resolve_loss("l1")
     for side in (False, True, False):
-        C.set_wgrad_side_stream(side)
+        VS.set_wgrad_side_stream(side)
         for i in range(4):
             train_step(engine, optimizer, *batches[i % len(batches)], 2, loss_fn)
         torch.cuda.synchronize()
@@ -41,7 +42,7 @@ def main():
         host.sort()
         print(f"side_stream={side}: wall {wall / steps * 1e3:.3f} ms/step; host enqueue: first 4 steps {[round(h * 1e3, 2) for h in host[:4]]} ms (fastest), "
               f"median {host[len(host) // 2] * 1e3:.2f} ms, all steps enqueued after {t_enq / steps * 1e3:.3f} ms/step", flush=True)
-    C.set_wgrad_side_stream(False)
+    VS.set_wgrad_side_stream(False)
 
 
 if __name__ == "__main__":

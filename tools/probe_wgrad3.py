@@ -4,6 +4,7 @@ import os
 import sys
 
 import torch
+import variant_switches as VS  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,11 +34,11 @@ def main():
         dys = [torch.randn(n, c, hw, hw, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(nbuf)]
         res = {}
         for name, flag in (("per_tap", False), ("all_taps", True)):
-            prev = C.set_wgrad3_all_taps(flag)
+            prev = VS.set_wgrad3_all_taps(flag)
             try:
                 res[name] = ev(lambda i: C.conv2d_wgrad(dys[i % nbuf], xs[i % nbuf], 3, 1, 1), 20)
             finally:
-                C.set_wgrad3_all_taps(prev)
+                VS.set_wgrad3_all_taps(prev)
         flop = 2.0 * n * hw * hw * c * c * 9
         print(f"{c:4d}->{c:4d} k3 H{hw:2d} N={n}: per-tap {res['per_tap']:7.1f} us ({flop / res['per_tap'] / 1e6:6.0f} TF)   "
               f"all-taps {res['all_taps']:7.1f} us ({flop / res['all_taps'] / 1e6:6.0f} TF)   x{res['per_tap'] / res['all_taps']:.2f}", flush=True)

@@ -18,6 +18,11 @@ Adam arithmetic, the initial weights and the batch order per seed. Deltas are pa
 buffers, Adam moments); every arm then trains the remaining epochs from it with the same batch order per seed, so the arms differ by their
 arithmetic over the converging phase only and the paired difference is not buried under the chaotic divergence of whole trajectories.
 
+Round 6: arm ``mixed<E>`` = the product's precision schedule (`train.py --amp_switch_epoch E`): ONE engine, float32 tile kernels for
+epochs < E, bf16 from epoch E on; its first E epochs are bit-identical to the ``float32`` arm's (deterministic kernels, same seed), so the paired
+difference measures exactly what the switch costs.
+
+    python tools/valmae_proxy.py --seeds 10 --epochs 24 --decay-at 16 --arms float32,mixed8,bf16 --ref float32 --out valmae_mixed
     python tools/valmae_proxy.py --seeds 10 --epochs 24 --decay-at 16 --batch 256 --arms bf16,lib_f32,lib_bf16 [--branch 16] [--out name]
     ->  gpurun_out/<name>.json (commit as profiles/rNN_<name>.json)"""
 import argparse
@@ -66,6 +71,10 @@ def make_task(device, n_train, n_val, seed=1234):
 ARMS = ("bf16", "float32", "lib_f32", "lib_bf16")
 
 
+def switch_epoch_of(arm):
+    return int(arm[5:]) if arm.startswith("mixed") else None
+
+
 def build_arm(arm, seed, device, init_state=None):
     """Model wrapper (call / .module / .parameters / .train / .eval) + optimizer for one arm; identical initial weights per seed."""
     from dirhip.optim import Adam
@@ -75,7 +84,7 @@ def build_arm(arm, seed, device, init_state=None):
     model = resnet50(fds=True, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
     if init_state is not None:
         model.load_state_dict(init_state["model"])
-    if arm in ("bf16", "float32"):
+    if arm in ("bf16", "float32") or arm.startswith("mixed"):
         eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if arm == "bf16" else None, channels_last=True)
         opt = Adam(eng.parameters(), lr=1e-3)
     else:
@@ -90,7 +99,7 @@ def build_arm(arm, seed, device, init_state=None):
     return eng, opt
 
 
-def train_epochs(eng, opt, task, seed, epoch0, epochs, batch, decay_at, lr0=1e-3):
+def train_epochs(eng, opt, task, seed, epoch0, epochs, batch, decay_at, lr0=1e-3, switch_epoch=None):
     from dirhip import lds
     from dirhip.train_loop import EpochFeatures, epoch_tail, resolve_loss, train_step
     y_train, y_val, x_train, x_val = task
@@ -108,6 +117,8 @@ def train_epochs(eng, opt, task, seed, epoch0, epochs, batch, decay_at, lr0=1e-3
             continue
         for gp in opt.param_groups:                                       # the reference's step schedule (train.py: adjust_learning_rate, x0.1), once
             gp["lr"] = lr0 * (0.1 if (decay_at and epoch >= decay_at) else 1.0)
+        if switch_epoch is not None:                                      # train.py --amp_switch_epoch
+            eng.set_amp_dtype(None if epoch < switch_epoch else torch.bfloat16)
         eng.train()
         idx = [perm[s:s + batch] for s in range(0, n - batch + 1, batch)]
         for ix in idx:
@@ -154,7 +165,7 @@ def main():
     ap.add_argument("--out", default="valmae_proxy")
     a = ap.parse_args()
     arms = [x for x in a.arms.split(",") if x]
-    assert all(x in ARMS for x in arms) and a.ref in arms
+    assert all(x in ARMS or x.startswith("mixed") for x in arms) and a.ref in arms
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     task = make_task(device, a.n_train, a.n_val)
@@ -172,7 +183,7 @@ def main():
         for arm in arms:
             t1 = time.time()
             eng, opt = build_arm(arm, seed if not a.branch else 1000, device, init_state=start)
-            train_epochs(eng, opt, task, seed, a.branch, a.epochs, a.batch, a.decay_at)
+            train_epochs(eng, opt, task, seed, a.branch, a.epochs, a.batch, a.decay_at, switch_epoch=switch_epoch_of(arm))
             r = evaluate(eng, task, a.batch)
             r["seconds"] = time.time() - t1
             res[arm].append(r)
@@ -188,7 +199,9 @@ def main():
                    f"batch {a.batch}, {a.epochs} epochs" + (f" (lr x0.1 from epoch {a.decay_at})" if a.decay_at else "") + ", the drop-in train_step / epoch_tail / validate / shot_metrics",
            "arms": {"bf16": "the product path (this repo's bf16 graph)", "float32": "the product's parity-exact float32 mode",
                     "lib_f32": "the reference's arithmetic on this GPU: plain torch modules, vendor-library float32 kernels (tools/library_resnet.py)",
-                    "lib_bf16": "the same library network under torch.autocast(bfloat16)"},
+                    "lib_bf16": "the same library network under torch.autocast(bfloat16)",
+                    **{x: f"the product's precision schedule (train.py --amp_switch_epoch {switch_epoch_of(x)}): float32 tile kernels for epochs < {switch_epoch_of(x)}, bf16 after"
+                       for x in arms if x.startswith("mixed")}},
            "form": (f"branch: every arm continues ONE {a.ref} run from epoch {a.branch} (weights, buffers, Adam moments), same batch order per seed" if a.branch
                     else "whole schedules, same initial weights and batch order per seed"),
            "seeds": a.seeds, "seed0": a.seed0, "reference_arm": a.ref, "per_seed": res,
