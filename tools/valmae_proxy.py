@@ -165,7 +165,9 @@ def main():
     ap.add_argument("--out", default="valmae_proxy")
     a = ap.parse_args()
     arms = [x for x in a.arms.split(",") if x]
-    assert all(x in ARMS or x.startswith("mixed") for x in arms) and a.ref in arms
+    assert all(x in ARMS or x.startswith("mixed") for x in arms)
+    assert a.ref in arms or not a.branch, "--branch needs its reference arm in --arms"       # (whole schedules: an absent --ref only drops the paired deltas;
+                                                                                              #  the arms are deterministic per seed, pair them with an earlier run's)
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     task = make_task(device, a.n_train, a.n_val)
@@ -212,7 +214,7 @@ def main():
                             for k in keys} for arm, rows in res.items()}
     out["paired_delta_vs_reference"] = {}
     for arm in arms:
-        if arm == a.ref:
+        if arm == a.ref or a.ref not in res:
             continue
         d = {}
         for k in keys:
