@@ -36,6 +36,8 @@ struct ConvF32P {
     const float* addend;       // [M][Ncol] added to the result (gradient accumulation of a fan-out)
     const float* addend2;      // COMPACT [N][H/2][W/2][Ncol], added at the even (h, w) pixels only (stride-2 1x1 sibling)
     const float* mask;         // [M][Ncol]: result zeroed where !(mask > 0) (ReLU backward of the tensor the gradient belongs to)
+    float* stats;              // forward tile kernel only: per 64-row slab of the output and channel, (sum, sum of squares) [slabs][2][Ncol] — the
+                               // statistics partials the following BatchNorm consumes (dir_bn_fwd_train_partials): no statistics pass over y
 };
 
 // 8 MFMA 32x32x2 on one staged K-step. A fragment: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31].
@@ -502,6 +504,13 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
                             slab[(wm * WM - 64 * h + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * TN + wn * WN + ni * 32 + fi] = acc[mi][ni][e];
             }
             __syncthreads();
+            if (MODE == FT_FWD && p.stats && t < TN && n0 + t < p.Ncol) {        // BatchNorm statistics of this slab: one thread per column, rows in order
+                float s1 = 0.0f, s2 = 0.0f;                                       // (rows past M hold exact zeros: their A rows were zero-filled)
+#pragma unroll 8
+                for (int r = 0; r < 64; ++r) { const float v = slab[r * TN + t]; s1 += v; s2 += v * v; }
+                float* so = p.stats + ((size_t)(mt * (TM / 64) + h) * 2) * p.Ncol + n0 + t;
+                so[0] = s1; so[p.Ncol] = s2;
+            }
 #pragma unroll
             for (int it = 0; it < 64 / RPI; ++it) {
                 const int lr = it * RPI + r4;
@@ -635,8 +644,14 @@ static ConvF32T ft_params(const ConvF32P& p, size_t a_elems, size_t b_elems) {
     return q;
 }
 
-extern "C" int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
-                                        int stride, int pad, int variant, dir_stream_t stream) {
+// rows of the statistics list of dir_conv_f32_fwd_stats: one per 64-row slab of the 128-row tiles
+extern "C" size_t dir_conv_f32_stats_rows(int N, int Ho, int Wo) {
+    const long long M = (long long)N * Ho * Wo;
+    return M > 0 ? (size_t)((M + 127) / 128) * 2 : 0;
+}
+
+static int cf_fwd_impl(const float* x, const float* w, float* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout, int R, int S,
+                       int stride, int pad, int variant, dir_stream_t stream) {
     int Ho, Wo;
     const int rc = cf_check(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
@@ -645,10 +660,15 @@ extern "C" int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y
     p.a = x; p.b = w; p.out = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = N * Ho * Wo; p.Ncol = Cout; p.K = R * S * Cin; p.klen = p.K;
-    p.addend = p.addend2 = p.mask = nullptr;
+    p.addend = p.addend2 = p.mask = nullptr; p.stats = nullptr;
     const size_t xe = (size_t)N * H * W * Cin, we = (size_t)Cout * p.K;
     const bool tile_ok = dir_aligned16(x) && dir_aligned16(w) && ft_ok(FT_FWD, p, xe, we);
     DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
+    if (stats) {                                                        // fused BatchNorm statistics: tile kernel + its LDS store loop only
+        DIR_RETURN_IF(!tile_ok || variant == DIR_CONV_F32_GATHER || (Cout & 3), DIR_EUNSUPPORTED);
+        DIR_RETURN_IF((size_t)stats_rows != dir_conv_f32_stats_rows(N, Ho, Wo), DIR_EINVAL);
+        p.stats = stats;
+    }
     if (tile_ok && variant != DIR_CONV_F32_GATHER) {
         const ConvF32T q = ft_params(p, xe, we);
         return p.Ncol > 64 ? ft_launch<128, 128, FT_FWD>(q, 1, dir_s(stream)) : ft_launch<128, 64, FT_FWD>(q, 1, dir_s(stream));
@@ -659,9 +679,22 @@ extern "C" int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y
     return DIR_OK;
 }
 
+extern "C" int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                        int stride, int pad, int variant, dir_stream_t stream) {
+    return cf_fwd_impl(x, w, y, nullptr, 0, N, H, W, Cin, Cout, R, S, stride, pad, variant, stream);
+}
+
 extern "C" int dir_conv_f32_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                                 int stride, int pad, dir_stream_t stream) {
-    return dir_conv_f32_fwd_variant(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
+    return cf_fwd_impl(x, w, y, nullptr, 0, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
+}
+
+// forward + the per-channel (sum, sum of squares) partials of y for the BatchNorm that follows ([stats_rows][2][Cout] f32, stats_rows =
+// dir_conv_f32_stats_rows): tile kernel geometries with Cout % 4 == 0 only (DIR_EUNSUPPORTED otherwise: the caller lets the BatchNorm count)
+extern "C" int dir_conv_f32_fwd_stats(const float* x, const float* w, float* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout,
+                                      int R, int S, int stride, int pad, dir_stream_t stream) {
+    DIR_RETURN_IF(!stats, DIR_EINVAL);
+    return cf_fwd_impl(x, w, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
 }
 
 extern "C" int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
@@ -676,7 +709,7 @@ extern "C" int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const
     p.a = dy; p.b = w; p.out = dx;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.M = N * H * W; p.Ncol = Cin; p.K = R * S * Cout; p.klen = p.K;
-    p.addend = addend; p.addend2 = addend_s2; p.mask = relu_mask;
+    p.addend = addend; p.addend2 = addend_s2; p.mask = relu_mask; p.stats = nullptr;
     const size_t ye = (size_t)N * Ho * Wo * Cout, we = (size_t)Cout * R * S * Cin;
     const bool tile_ok = dir_aligned16(dy) && dir_aligned16(w) && ft_ok(FT_DGRAD, p, ye, we);
     DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
@@ -709,7 +742,7 @@ static bool cf_wgrad_plan(int N, int H, int W, int Cin, int Cout, int R, int S, 
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     p->N = N; p->H = H; p->W = W; p->Cin = Cin; p->Ho = Ho; p->Wo = Wo; p->Cout = Cout; p->R = R; p->S = S; p->stride = stride; p->pad = pad;
     p->M = Cout; p->Ncol = R * S * Cin; p->K = N * Ho * Wo;
-    p->addend = p->addend2 = p->mask = nullptr;
+    p->addend = p->addend2 = p->mask = nullptr; p->stats = nullptr;
     const bool tile_ok = ft_ok(FT_WGRAD, *p, (size_t)p->K * Cout, (size_t)N * H * W * Cin);
     const bool tile = tile_ok && variant != DIR_CONV_F32_GATHER;
     if (tile) { ft_wgrad_tile(*p, TM, TN); *splits = ft_wgrad_splits(p->M, p->Ncol, p->K, *TM, *TN, &p->klen); }

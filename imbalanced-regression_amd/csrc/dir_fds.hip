@@ -70,20 +70,18 @@ extern "C" int dir_fds_bin_index(const float* labels, int n, int bucket_start, i
 // K2: per-bin (count, mean, M2) in one streaming pass
 // =============================================================================================
 // Stage G1-G3: stable counting sort of the row indices by bin (rows with bin < 0 dropped).
-//   tile  = GROUP_TILE consecutive rows handled by ONE workgroup, a quarter per wavefront (ranks inside a wavefront's rows come from
+//   tile  = GROUP_TILE consecutive rows handled by ONE wavefront (so ranks inside a tile come from
 //           ballots in program order: stable and deterministic without atomics on the data path);
 // Stage P : every "piece" (<= PIECE_ROWS sorted rows of one bin) x (column tile) is reduced in
 //           float64 registers around the shift K = first row of the bin;
 // Stage C : pieces of a bin are combined in index order -> (count, mean, M2).
-#define GROUP_WAVES 4
-#define GROUP_WROWS 1024      // rows per grouping wavefront
-#define GROUP_TILE (GROUP_WAVES * GROUP_WROWS)   // rows per grouping workgroup (tile): few enough tiles that the prefix over tiles is one LDS-resident scan
+#define GROUP_TILE 256        // rows per grouping wavefront: N / 256 wavefronts keep all 256 CUs busy at N = 191 509
 #define PIECE_ROWS 256        // rows per piece: 2 x fewer float64 partials to write and re-read than 128 (52 -> 26 MB at N = 191 509)
 #define PIECE_UNROLL 8
 
 struct ScatterWs {            // carved from the caller's workspace (all 256-B aligned)
     int32_t* tile_hist;       // [ntiles][nb]   counts, then exclusive prefix over tiles
-    int32_t* totals;          // [nb]           (unused since round 6)
+    int32_t* totals;          // [nb]           rows per bin
     int32_t* offsets;         // [nb+1]         start of each bin in perm
     int32_t* bin_piece0;      // [nb+1]         first piece of each bin
     int32_t* npieces;         // [1]
@@ -127,125 +125,109 @@ extern "C" size_t dir_fds_scatter_stats_workspace(int n, int C, int nb) {
     return carve_ws(nullptr, n, C, nb).bytes;
 }
 
-// G1: one workgroup (4 wavefronts) per tile of GROUP_TILE rows; per-wavefront LDS histograms (each wavefront owns a quarter of the tile, in row
-// order), summed to the tile's counts. Round 6: tiles of 4096 rows instead of 256-row wavefront tiles — 136 instead of 2 166 tiles at the NYUD2
-// map's N = 554 496 — so that the prefix over tiles (G2) is ONE small LDS-resident scan instead of two latency-bound launches
-// (profiles/r05_fds_scatter_narrow_breakdown.txt: 19 of the call's 93 us).
-__global__ void __launch_bounds__(DIR_TPB)
+// G1: one wavefront per tile; LDS histogram.
+__global__ void __launch_bounds__(DIR_WAVE)
 fds_group_hist_kernel(const int32_t* __restrict__ bins, int n, int nb, int32_t* __restrict__ tile_hist) {
-    extern __shared__ __attribute__((aligned(16))) int32_t hist[];       // [GROUP_WAVES][nb]
-    const int t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE, tile = blockIdx.x;
-    for (int i = t; i < GROUP_WAVES * nb; i += DIR_TPB) hist[i] = 0;
+    extern __shared__ __attribute__((aligned(16))) int32_t hist[];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int b = lane; b < nb; b += DIR_WAVE) hist[b] = 0;
     __syncthreads();
-    const int r0 = tile * GROUP_TILE + wid * GROUP_WROWS;
-    const int r1 = min(n, r0 + GROUP_WROWS);
-    for (int r = r0 + lane; r < r1; r += DIR_WAVE) {
+    const int r0 = tile * GROUP_TILE;
+    for (int r = r0 + lane; r < min(n, r0 + GROUP_TILE); r += DIR_WAVE) {
         const int b = bins[r];
-        if (b >= 0 && b < nb) atomicAdd(&hist[wid * nb + b], 1);          // LDS integer atomic: order-free
+        if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);        // LDS integer atomic: order-free
     }
     __syncthreads();
-    for (int b = t; b < nb; b += DIR_TPB) {
-        int c = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < GROUP_WAVES; ++w2) c += hist[w2 * nb + b];
-        tile_hist[(size_t)tile * nb + b] = c;
-    }
+    for (int b = lane; b < nb; b += DIR_WAVE) tile_hist[(size_t)tile * nb + b] = hist[b];
 }
 
-// G2: ONE workgroup: the tile counts [ntiles][nb] are brought into LDS by slabs of tiles, turned into exclusive prefixes over the tiles per
-// bin (thread = bin, a running carry per bin across the slabs) and written back; then the offsets over bins and the piece table.
-#define GROUP_SCAN_TPB 1024
-__global__ void __launch_bounds__(GROUP_SCAN_TPB)
-fds_group_scan_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int slab_tiles, int maxpieces,
+// Exclusive prefix of one value per thread over the 256 threads of a workgroup (wavefront shuffles + one LDS hop), plus the workgroup total.
+__device__ __forceinline__ int fds_block_excl_scan(int v, int* total) {
+    __shared__ int32_t wsum[DIR_TPB / DIR_WAVE];
+    const int t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < DIR_WAVE; o <<= 1) { const int u = __shfl_up(incl, o, DIR_WAVE); if (lane >= o) incl += u; }
+    __syncthreads();                                       // (wsum of a previous call is no longer being read)
+    if (lane == DIR_WAVE - 1) wsum[wid] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < DIR_TPB / DIR_WAVE; ++k) { const int w = wsum[k]; if (k < wid) woff += w; tot += w; }
+    *total = tot;
+    return woff + incl - v;
+}
+
+// G2a: one workgroup per bin: exclusive prefix of that bin's counts over the tiles, total per bin. Round 6: a thread owns GS_PER CONSECUTIVE
+// tiles — all its loads are independent (one L2 round trip instead of a dependent load -> scan -> store chain per 256 tiles: 10.9 -> ~3 us at
+// 2 166 tiles), prefix inside the thread, ONE workgroup scan over the thread totals.
+#define GS_PER 16
+__global__ void __launch_bounds__(DIR_TPB)
+fds_group_scan_tiles_kernel(int32_t* __restrict__ tile_hist, int ntiles, int nb, int32_t* __restrict__ totals) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < ntiles; base += DIR_TPB * GS_PER) {
+        int v[GS_PER];
+        const int t0 = base + t * GS_PER;
+#pragma unroll
+        for (int u = 0; u < GS_PER; ++u) v[u] = (t0 + u < ntiles) ? tile_hist[(size_t)(t0 + u) * nb + b] : 0;
+        int sum = 0;
+#pragma unroll
+        for (int u = 0; u < GS_PER; ++u) { const int c = v[u]; v[u] = sum; sum += c; }
+        int tot;
+        const int off = carry + fds_block_excl_scan(sum, &tot);
+#pragma unroll
+        for (int u = 0; u < GS_PER; ++u) if (t0 + u < ntiles) tile_hist[(size_t)(t0 + u) * nb + b] = off + v[u];
+        carry += tot;
+    }
+    if (t == 0) totals[b] = carry;
+}
+
+// G2b: single workgroup: offsets over bins (workgroup scan over the bins, 256 at a time), piece table.
+__global__ void __launch_bounds__(DIR_TPB)
+fds_group_scan_kernel(const int32_t* __restrict__ totals, int nb, int maxpieces,
                       int32_t* __restrict__ offsets, int32_t* __restrict__ bin_piece0,
                       int32_t* __restrict__ npieces, int32_t* __restrict__ piece_bin,
                       int32_t* __restrict__ piece_p0, int32_t* __restrict__ piece_p1) {
-    extern __shared__ __attribute__((aligned(16))) int32_t sh[];         // slab[slab_tiles][nb], carry[nb], tot[nb + 1], pcs[nb + 1]
-    int32_t* slab = sh;
-    int32_t* carry = sh + (size_t)slab_tiles * nb;
-    int32_t* tot = carry + nb;
-    int32_t* pcs = tot + (nb + 1);
     const int t = threadIdx.x;
-    for (int b = t; b < nb; b += GROUP_SCAN_TPB) carry[b] = 0;
-    __syncthreads();
-    for (int t0 = 0; t0 < ntiles; t0 += slab_tiles) {
-        const int nt = min(slab_tiles, ntiles - t0);
-        const int cnt = nt * nb;
-        __syncthreads();
-        for (int i = t; i < cnt; i += GROUP_SCAN_TPB) slab[i] = tile_hist[(size_t)t0 * nb + i];      // contiguous: all loads independent
-        __syncthreads();
-        for (int b = t / DIR_WAVE; b < nb; b += GROUP_SCAN_TPB / DIR_WAVE) {                          // one wavefront per bin, lanes over the slab's tiles
-            const int lane = t & (DIR_WAVE - 1);
-            int c = carry[b];
-            for (int k0 = 0; k0 < nt; k0 += DIR_WAVE) {
-                const int k = k0 + lane;
-                const int v = k < nt ? slab[k * nb + b] : 0;
-                int incl = v;
-#pragma unroll
-                for (int o = 1; o < DIR_WAVE; o <<= 1) { const int u = __shfl_up(incl, o, DIR_WAVE); if (lane >= o) incl += u; }
-                if (k < nt) slab[k * nb + b] = c + incl - v;
-                c += __shfl(incl, DIR_WAVE - 1, DIR_WAVE);
+    int co = 0, cp = 0;                                    // running totals of rows / pieces over the bins before this chunk
+    for (int base = 0; base < nb; base += DIR_TPB) {
+        const int b = base + t;
+        const int c = b < nb ? totals[b] : 0;
+        const int np = (c + PIECE_ROWS - 1) / PIECE_ROWS;
+        int to, tp;
+        const int o0 = co + fds_block_excl_scan(c, &to);
+        int k = cp + fds_block_excl_scan(np, &tp);
+        if (b < nb) {
+            offsets[b] = o0; bin_piece0[b] = k;
+            const int o1 = o0 + c;
+            for (int p0 = o0; p0 < o1; p0 += PIECE_ROWS, ++k) {
+                if (k < maxpieces) { piece_bin[k] = b; piece_p0[k] = p0; piece_p1[k] = min(p0 + PIECE_ROWS, o1); }
             }
-            if (lane == 0) carry[b] = c;
         }
-        __syncthreads();
-        for (int i = t; i < cnt; i += GROUP_SCAN_TPB) tile_hist[(size_t)t0 * nb + i] = slab[i];
+        co += to; cp += tp;
     }
-    __syncthreads();
-    if (t == 0) {                                          // nb is a few thousand at most
-        int o = 0, p = 0;
-        for (int b = 0; b < nb; ++b) {
-            const int c = carry[b];
-            offsets[b] = o; bin_piece0[b] = p;
-            tot[b] = o; pcs[b] = p;
-            o += c; p += (c + PIECE_ROWS - 1) / PIECE_ROWS;
-        }
-        offsets[nb] = o; bin_piece0[nb] = p; tot[nb] = o; pcs[nb] = p;
-        *npieces = p;
-    }
-    __syncthreads();
-    for (int b = t; b < nb; b += GROUP_SCAN_TPB) {
-        const int o0 = tot[b], o1 = tot[b + 1];
-        int k = pcs[b];
-        for (int p0 = o0; p0 < o1; p0 += PIECE_ROWS, ++k) {
-            if (k < maxpieces) { piece_bin[k] = b; piece_p0[k] = p0; piece_p1[k] = min(p0 + PIECE_ROWS, o1); }
-        }
-    }
+    if (t == 0) { offsets[nb] = co; bin_piece0[nb] = cp; *npieces = cp; }
 }
 
-// G3: one workgroup per tile; stable placement. The wavefronts of a tile own consecutive quarters of its rows: wavefront w starts every bin's
-// cursor at (bin offset) + (rows of that bin in earlier tiles) + (rows of that bin in wavefronts < w of this tile) — the per-wavefront
-// histograms are recounted here (16 KB of bins per tile, L2 resident). For each chunk of 64 rows the lanes that share a bin are found with one
+// G3: one wavefront per tile; stable placement. For each chunk of 64 rows the lanes that share a bin are found with one
 // ballot per BIT of the bin index ("match-any": 7 ballots for 100 bins, no loop over the distinct bins of the chunk, no
 // barrier), the lowest such lane bumps the bin's cursor once (LDS atomic of ONE lane per bin and chunk, chunks in program
 // order: the result is the stable order, independent of timing) and every lane stores its row at base + (number of lower
-// lanes of its bin).
-__global__ void __launch_bounds__(DIR_TPB)
+// lanes of its bin). Round 1 looped over the distinct bins of a chunk with two barriers each: 22-27 us, latency bound.
+__global__ void __launch_bounds__(DIR_WAVE)
 fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbits,
                        const int32_t* __restrict__ tile_prefix, const int32_t* __restrict__ offsets,
                        int32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int32_t cursor[];     // [GROUP_WAVES][nb]
-    const int t = threadIdx.x, lane = t & (DIR_WAVE - 1), wid = t / DIR_WAVE, tile = blockIdx.x;
-    for (int i = t; i < GROUP_WAVES * nb; i += DIR_TPB) cursor[i] = 0;
+    extern __shared__ __attribute__((aligned(16))) int32_t cursor[];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int b = lane; b < nb; b += DIR_WAVE) cursor[b] = offsets[b] + tile_prefix[(size_t)tile * nb + b];
     __syncthreads();
-    const int r0 = tile * GROUP_TILE + wid * GROUP_WROWS;
-    const int r1 = min(n, r0 + GROUP_WROWS);
-    for (int r = r0 + lane; r < r1; r += DIR_WAVE) {
-        const int b = bins[r];
-        if (b >= 0 && b < nb) atomicAdd(&cursor[wid * nb + b], 1);
-    }
-    __syncthreads();
-    for (int b = t; b < nb; b += DIR_TPB) {                              // counts -> start cursors of the four wavefronts
-        int c = offsets[b] + tile_prefix[(size_t)tile * nb + b];
-#pragma unroll
-        for (int w2 = 0; w2 < GROUP_WAVES; ++w2) { const int v = cursor[w2 * nb + b]; cursor[w2 * nb + b] = c; c += v; }
-    }
-    __syncthreads();
-    int32_t* cur = cursor + wid * nb;
+    const int r0 = tile * GROUP_TILE;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int c = r0; c < r1; c += DIR_WAVE) {
-        const int r = c + lane;
-        int b = (r < r1) ? bins[r] : -1;
+    for (int c = 0; c < GROUP_TILE; c += DIR_WAVE) {
+        const int r = r0 + c + lane;
+        int b = (r < n) ? bins[r] : -1;
         if (b >= nb) b = -1;
         const bool valid = b >= 0;
         unsigned long long mask = __ballot(valid);
@@ -257,10 +239,11 @@ fds_group_place_kernel(const int32_t* __restrict__ bins, int n, int nb, int nbit
         if (valid) {                                            // mask = the valid lanes of this chunk with my bin
             const int leader = __ffsll((long long)mask) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&cur[b], __popcll(mask));
+            if (lane == leader) base = atomicAdd(&cursor[b], __popcll(mask));
             base = __shfl(base, leader, DIR_WAVE);
             perm[base + __popcll(mask & lt)] = r;
         }
+        if (r0 + c + DIR_WAVE >= n) break;
     }
 }
 
@@ -423,25 +406,20 @@ extern "C" int dir_fds_scatter_stats(const void* feats, int dtype, const int32_t
     ScatterWs w = carve_ws(workspace, n, C, nb);
     DIR_RETURN_IF(workspace_bytes < w.bytes, DIR_EWORKSPACE);
     const float* f = static_cast<const float*>(feats);
-    const size_t lds_nb = sizeof(int32_t) * (size_t)nb * GROUP_WAVES;
-    DIR_RETURN_IF(lds_nb > 128 * 1024, DIR_EUNSUPPORTED);                        // (nb <= 8192: one LDS counter per bin and grouping wavefront)
-    DIR_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fds_group_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_TPB), lds_nb, s, bins, n, nb, w.tile_hist);
+    const size_t lds_nb = sizeof(int32_t) * (size_t)nb;
+    DIR_RETURN_IF(lds_nb > 64 * 1024, DIR_EUNSUPPORTED);                          // (one LDS counter per bin in the grouping wavefronts: nb <= 16 384)
+
+    hipLaunchKernelGGL(fds_group_hist_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s, bins, n, nb, w.tile_hist);
     DIR_LAUNCH_CHECK();
-    // the scan keeps a slab of tiles + 3 bin-sized arrays in LDS: as many tiles per slab as fit 150 KB
-    int slab_tiles = (int)((150 * 1024 / sizeof(int32_t) - 3 * (size_t)(nb + 1)) / (size_t)nb);
-    if (slab_tiles > w.ntiles) slab_tiles = w.ntiles;
-    DIR_RETURN_IF(slab_tiles < 1, DIR_EUNSUPPORTED);
-    const size_t lds_scan = sizeof(int32_t) * ((size_t)slab_tiles * nb + 3 * (size_t)(nb + 1));
-    hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(GROUP_SCAN_TPB), lds_scan, s,
-                       w.tile_hist, w.ntiles, nb, slab_tiles, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
+    hipLaunchKernelGGL(fds_group_scan_tiles_kernel, dim3(nb), dim3(DIR_TPB), 0, s, w.tile_hist, w.ntiles, nb, w.totals);
+    DIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fds_group_scan_kernel, dim3(1), dim3(DIR_TPB), 0, s,
+                       w.totals, nb, w.maxpieces, w.offsets, w.bin_piece0, w.npieces,
                        w.piece_bin, w.piece_p0, w.piece_p1);
     DIR_LAUNCH_CHECK();
     int nbits = 0;
     while ((1 << nbits) < nb) ++nbits;
-    hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_TPB), lds_nb, s,
+    hipLaunchKernelGGL(fds_group_place_kernel, dim3(w.ntiles), dim3(DIR_WAVE), lds_nb, s,
                        bins, n, nb, nbits, w.tile_hist, w.offsets, w.perm);
     DIR_LAUNCH_CHECK();
     const bool vec4 = (C % 4 == 0) && dir_aligned16(feats);

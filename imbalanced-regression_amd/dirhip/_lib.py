@@ -119,6 +119,8 @@ SIGNATURES = {
     "dir_conv_f32_wgrad_workspace": (c_size_t, [c_int] * 9),
     "dir_conv_f32_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "dir_conv_f32_fwd_variant": (c_int, [c_void_p] * 3 + [c_int] * 10 + [c_void_p]),
+    "dir_conv_f32_stats_rows": (c_size_t, [c_int] * 3),
+    "dir_conv_f32_fwd_stats": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dir_conv_f32_dgrad_variant": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "dir_conv_f32_wgrad_variant": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_int, c_void_p]),
     "dir_maxpool3x3s2_f32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -563,16 +563,16 @@ def conv_bn_input(x, conv, want_stats, alias_input=False, relu_flag=None):
     persistent buffers that are rewritten in place: a backward pass must run before the optimizer step that follows
     its forward pass (as in any training loop)."""
     if x.dtype == torch.float32:
-        # float32 parity mode: the same node contract on the exact-float32 kernels (statistics are then computed by the
-        # BatchNorm node itself)
+        # float32 parity mode: the same node contract on the exact-float32 kernels (round 6: the tile kernels form the BatchNorm statistics in
+        # their store loop too; geometries on the gather kernel return None and the BatchNorm node counts itself)
         from .conv_f32 import conv_graph_f32
         grad_mode = torch.is_grad_enabled()
         aliasing = bool(alias_input and grad_mode and x.requires_grad)
         relu_input = bool(relu_flag is not None and aliasing and conv.stride[0] == 1 and not relu_flag[0])
         if relu_input:
             relu_flag[0] = True
-        y, alias = conv_graph_f32(x, conv, aliasing, relu_input)
-        return (y, None, alias if alias is not None else x) if alias_input else (y, None)
+        y, alias, stats = conv_graph_f32(x, conv, aliasing, relu_input, want_stats=bool(want_stats))
+        return (y, stats, alias if alias is not None else x) if alias_input else (y, stats)
     w = conv.weight
     w16, w16_rot = _prepared(conv)
     if x.dtype != torch.bfloat16:
@@ -607,8 +607,8 @@ def projection_pair(x, conv1, conv_d, want_stats, relu_flag=None):
         relu_input = bool(relu_flag is not None and torch.is_grad_enabled() and x.requires_grad and not relu_flag[0])
         if relu_input:
             relu_flag[0] = True
-        y1, yd = projection_pair_f32(x, conv1, conv_d, relu_input)
-        return y1, None, yd, None
+        y1, yd, s1, sd = projection_pair_f32(x, conv1, conv_d, relu_input, want_stats=bool(want_stats))
+        return y1, s1, yd, sd
     w1_16, w1_rot = _prepared(conv1)
     wd_16, wd_rot = _prepared(conv_d)
     assert w1_rot is not None and wd_rot is not None

@@ -25,14 +25,31 @@ def _f32(t):
 GATHER, TILE = 1, 2                     # DIR_CONV_F32_GATHER / DIR_CONV_F32_TILE: force a kernel (0 = the product's choice: tile where applicable)
 
 
-def conv2d_f32_fwd(x, w, stride, padding, variant=0):
-    """x [N, Cin, H, W], w [Cout, Cin, R, S]: float32 channels_last device tensors -> y float32 channels_last."""
+def stats_fusable(x, w):
+    """Can the forward of this geometry carry the BatchNorm statistics of its result (tile kernel + its LDS store loop: whole 16-channel K-steps,
+    Cout % 4 == 0, 32-bit byte offsets)? The rule of ``dir_conv_f32_fwd_stats``."""
+    return x.shape[1] % 16 == 0 and w.shape[0] % 4 == 0 and x.numel() * 4 < 2 ** 31 and w.numel() * 4 < 2 ** 31
+
+
+def conv2d_f32_fwd(x, w, stride, padding, variant=0, want_stats=False):
+    """x [N, Cin, H, W], w [Cout, Cin, R, S]: float32 channels_last device tensors -> y float32 channels_last. ``want_stats``: returns
+    ``(y, partial)`` with the per-channel (sum, sum of squares) partials ``[rows][2][Cout]`` of y for the BatchNorm that follows, formed in
+    the kernel's store loop (None where the geometry runs on the gather kernel: the BatchNorm then counts itself)."""
     n, cin, h, wd = x.shape
     cout, cin2, r, s = w.shape
     assert cin == cin2, (x.shape, w.shape)
     ho = (h + 2 * padding - r) // stride + 1
     wo = (wd + 2 * padding - s) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if want_stats:
+        if variant != 0 or not stats_fusable(x, w):
+            return conv2d_f32_fwd(x, w, stride, padding, variant), None
+        rows = L.lib().dir_conv_f32_stats_rows(n, ho, wo)
+        stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().dir_conv_f32_fwd_stats(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), rows, n, h, wd, cin, cout, r, s, stride, padding,
+                                                   L.stream_ptr(x.device)), "dir_conv_f32_fwd_stats")
+        return y, stats
     with torch.cuda.device(x.device):
         L.check(L.lib().dir_conv_f32_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, cin, cout, r, s, stride, padding, variant,
                                                  L.stream_ptr(x.device)), "dir_conv_f32_fwd")
@@ -173,20 +190,22 @@ def global_avgpool_flat_f32(x):
 # on store; the stride-2 downsample gradient in compact form): resnet.py builds ONE graph, these are its float32 kernels.
 class _ConvGraphF32Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, alias_input, relu_input):
+    def forward(ctx, x, weight, stride, padding, alias_input, relu_input, want_stats=False):
         ctx.set_materialize_grads(False)
         ctx.stride, ctx.padding, ctx.relu_input = stride, padding, relu_input
         x32, w32 = _nhwc(x), _nhwc(weight.detach())
-        y = conv2d_f32_fwd(x32, w32, stride, padding)
+        y, stats = conv2d_f32_fwd(x32, w32, stride, padding, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w32, stride, padding), None)
         ctx.save_for_backward(x32, w32)
-        return (y, x) if alias_input else (y, None)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, (x if alias_input else None), stats
 
     @staticmethod
-    def backward(ctx, dy, dalias=None):
+    def backward(ctx, dy, dalias=None, dstats=None):
         x, w32 = ctx.saved_tensors
         if dy is None:                                                           # only the alias output was used
             assert not ctx.relu_input
-            return dalias, None, None, None, None, None
+            return dalias, None, None, None, None, None, None
         dy = _nhwc(_f32(dy))
         dalias = None if dalias is None else _nhwc(_f32(dalias))
         dx = None
@@ -196,26 +215,30 @@ class _ConvGraphF32Fn(torch.autograd.Function):
         elif dalias is not None:
             dx = dalias
         dw = conv2d_f32_wgrad(dy, x, w32.shape[2:], ctx.stride, ctx.padding)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
-def conv_graph_f32(x, conv, alias_input, relu_input):
-    return _ConvGraphF32Fn.apply(x, conv.weight, conv.stride[0], conv.padding[0], alias_input, relu_input)
+def conv_graph_f32(x, conv, alias_input, relu_input, want_stats=False):
+    """Returns ``(y, alias or None, BatchNorm statistic partials of y or None)``."""
+    return _ConvGraphF32Fn.apply(x, conv.weight, conv.stride[0], conv.padding[0], alias_input, relu_input, want_stats)
 
 
 class _ProjectionPairF32Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, wd, stride_d, relu_input):
+    def forward(ctx, x, w1, wd, stride_d, relu_input, want_stats=False):
         ctx.set_materialize_grads(False)
         ctx.stride_d, ctx.relu_input = stride_d, relu_input
         x32, w1_32, wd_32 = _nhwc(x), _nhwc(w1.detach()), _nhwc(wd.detach())
-        y1 = conv2d_f32_fwd(x32, w1_32, 1, 0)
-        yd = conv2d_f32_fwd(x32, wd_32, stride_d, 0)
+        y1, s1 = conv2d_f32_fwd(x32, w1_32, 1, 0, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w1_32, 1, 0), None)
+        yd, sd = conv2d_f32_fwd(x32, wd_32, stride_d, 0, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, wd_32, stride_d, 0), None)
         ctx.save_for_backward(x32, w1_32, wd_32)
-        return y1, yd
+        for st in (s1, sd):
+            if st is not None:
+                ctx.mark_non_differentiable(st)
+        return y1, yd, s1, sd
 
     @staticmethod
-    def backward(ctx, dy1, dyd):
+    def backward(ctx, dy1, dyd, ds1=None, dsd=None):
         x, w1, wd = ctx.saved_tensors
         if dy1 is None:
             raise L.DirHipError("projection pair: conv1's output received no gradient")
@@ -232,8 +255,9 @@ class _ProjectionPairF32Fn(torch.autograd.Function):
             dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, addend_s2=compact, relu_mask=mask)
         dw1 = conv2d_f32_wgrad(dy1, x, (1, 1), 1, 0)
         dwd = conv2d_f32_wgrad(dyd, x, (1, 1), ctx.stride_d, 0) if dyd is not None else None
-        return (dx if ctx.needs_input_grad[0] else None), dw1, dwd, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dw1, dwd, None, None, None
 
 
-def projection_pair_f32(x, conv1, conv_d, relu_input):
-    return _ProjectionPairF32Fn.apply(x, conv1.weight, conv_d.weight, conv_d.stride[0], relu_input)
+def projection_pair_f32(x, conv1, conv_d, relu_input, want_stats=False):
+    """Returns ``(y1, yd, statistic partials of y1 or None, of yd or None)``."""
+    return _ProjectionPairF32Fn.apply(x, conv1.weight, conv_d.weight, conv_d.stride[0], relu_input, want_stats)

@@ -569,6 +569,13 @@ int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, in
 int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
                                const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad, int variant, dir_stream_t stream);
+/* forward + BatchNorm statistics (ABI 3): the per-channel (sum, sum of squares) partials of y, one row per 64-row slab of the output
+ * ([stats_rows][2][Cout] f32, stats_rows = dir_conv_f32_stats_rows(N, Ho, Wo)), formed in the tile kernel's store loop — what
+ * dir_bn_fwd_train_partials consumes instead of a statistics pass over y (as dir_conv_fwd does for the bf16 path).  Tile-kernel
+ * geometries with Cout % 4 == 0 only; DIR_EUNSUPPORTED otherwise (the caller then lets the BatchNorm count). */
+size_t dir_conv_f32_stats_rows(int N, int Ho, int Wo);
+int dir_conv_f32_fwd_stats(const float* x, const float* w, float* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout,
+                           int R, int S, int stride, int pad, dir_stream_t stream);
 int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad, void* workspace, size_t workspace_bytes, int variant, dir_stream_t stream);
 /* float32 NHWC pools of the parity mode: MaxPool2d(3, 2, 1) with an argmax byte (resnet.py:82,131) and the global

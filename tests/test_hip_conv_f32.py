@@ -98,6 +98,35 @@ def test_conv_f32_tile_kernels_vs_gather_and_float64(case):
     assert torch.equal(conv2d_f32_wgrad(dyg, xg, (k, k), stride, pad, variant=TILE), dw_t)       # fixed-order split-K: reproducible
 
 
+@pytest.mark.parametrize("case", [(2, 64, 14, 14, 64, 1, 1, 0), (3, 64, 14, 14, 128, 3, 2, 1), (2, 48, 10, 6, 80, 3, 1, 1), (4, 256, 14, 14, 1024, 1, 1, 0)])
+def test_conv_f32_forward_carries_the_batchnorm_statistics(case):
+    """dir_conv_f32_fwd_stats: y identical to the plain forward, and the per-slab (sum, sum of squares) partials add up to the column sums of y
+    (float32 sums over 64 rows, compared in float64 at 1e-6 of the column's scale); rows past M contribute nothing."""
+    from dirhip.conv_f32 import conv2d_f32_fwd, stats_fusable
+    n, cin, h, w, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.1).cuda().contiguous(memory_format=torch.channels_last)
+    assert stats_fusable(x, wt)
+    y, part = conv2d_f32_fwd(x, wt, stride, pad, want_stats=True)
+    assert torch.equal(y, conv2d_f32_fwd(x, wt, stride, pad))
+    m = y.numel() // cout
+    assert part.shape == ((m + 127) // 128 * 2, 2, cout)
+    y2 = y.permute(0, 2, 3, 1).reshape(m, cout).double()
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    scale = y2.abs().sum(0)
+    assert ((s1 - y2.sum(0)).abs() <= 1e-6 * scale + 1e-12).all()
+    assert ((s2 - (y2 * y2).sum(0)).abs() <= 1e-6 * (y2 * y2).sum(0) + 1e-12).all()
+    # per slab: exactly the rows of that slab
+    for r in range(part.shape[0]):
+        rows = y2[r * 64:(r + 1) * 64]
+        assert ((part[r, 0].double() - rows.sum(0)).abs() <= 2e-6 * rows.abs().sum(0) + 1e-12).all(), r
+    # the stem (Cin = 3) runs on the gather kernel: no fused statistics, the BatchNorm counts itself
+    xs = torch.randn(2, 3, 16, 16).cuda().contiguous(memory_format=torch.channels_last)
+    ws = torch.randn(64, 3, 7, 7).cuda().contiguous(memory_format=torch.channels_last)
+    assert conv2d_f32_fwd(xs, ws, 2, 3, want_stats=True)[1] is None
+
+
 def test_conv_f32_tile_variant_refuses_what_it_does_not_take():
     from dirhip import _lib as L
     from dirhip.conv_f32 import TILE, conv2d_f32_fwd
