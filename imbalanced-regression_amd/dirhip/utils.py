@@ -104,12 +104,17 @@ def save_checkpoint(args, state, is_best, prefix=''):
 
 
 class _CalibrateFn(torch.autograd.Function):
+    """Out of place (utils.py:106-107) or, ``inplace``, on ``matrix`` itself (utils.py:100-104: ``matrix[:, valid] = ...; return matrix``)."""
+
     @staticmethod
-    def forward(ctx, matrix, m1, v1, m2, v2, clip_min, clip_max):
+    def forward(ctx, matrix, m1, m2, scale, inplace):
         c = matrix.shape[1]
-        scale = ops.prepare_scale(v1.reshape(1, c).contiguous(), v2.reshape(1, c).contiguous(), clip_min, clip_max)
         bins = torch.zeros(matrix.shape[0], dtype=torch.int32, device=matrix.device)
-        out = matrix.clone(memory_format=torch.contiguous_format)
+        if inplace:
+            ctx.mark_dirty(matrix)
+            out = matrix
+        else:
+            out = matrix.clone(memory_format=torch.contiguous_format)
         ops.calibrate_fwd_(out, bins, m1.reshape(1, c).contiguous(), scale, m2.reshape(1, c).contiguous())
         ctx.save_for_backward(bins, scale)
         return out
@@ -117,17 +122,28 @@ class _CalibrateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         bins, scale = ctx.saved_tensors
-        return ops.calibrate_bwd(grad_out, bins, scale), None, None, None, None, None, None
+        return ops.calibrate_bwd(grad_out.contiguous(), bins, scale), None, None, None, None
 
 
 def calibrate_mean_var(matrix, m1, v1, m2, v2, clip_min=0.1, clip_max=10):
-    """utils.py:97-107 on the GPU: ``(matrix - m1) * sqrt(clamp(v2 / v1)) + m2`` for the columns with
-    ``v1 != 0``, the input unchanged when ``sum(v1) < 1e-10``. matrix [n, C]; m1, v1, m2, v2 [C].
-    Always returns a new tensor (the reference returns the input object itself on two of its three branches)."""
+    """utils.py:97-107 on the GPU, with the reference's three branches AND their object semantics: ``sum(v1) < 1e-10`` -> the input object, untouched;
+    some ``v1 == 0`` -> the input is calibrated IN PLACE on the columns with ``v1 != 0`` and returned itself (autograd sees an in-place operation,
+    as in the reference); otherwise a NEW tensor ``(matrix - m1) * sqrt(clamp(v2 / v1)) + m2``. matrix [n, C]; m1, v1, m2, v2 [C]. Which branch it
+    is comes from the per-column multipliers ``dir_fds_prepare_scale`` emits (-1 = column untouched) with one host read, where the reference
+    syncs twice (``if torch.sum(v1) < 1e-10``, ``if (v1 == 0.).any()``)."""
     for t, nm in ((matrix, "matrix"), (m1, "m1"), (v1, "v1"), (m2, "m2"), (v2, "v2")):
         L.require_device_tensor(t if t.is_contiguous() else t.contiguous(), torch.float32, nm)
     assert matrix.dim() == 2
-    return _CalibrateFn.apply(matrix, m1, v1, m2, v2, float(clip_min), float(clip_max))
+    c = matrix.shape[1]
+    scale = ops.prepare_scale(v1.reshape(1, c).contiguous(), v2.reshape(1, c).contiguous(), float(clip_min), float(clip_max))
+    untouched = int((scale < 0).sum().item())
+    if untouched == c:                                     # utils.py:98-99 (or every column has v1 == 0: the in-place branch would touch nothing)
+        return matrix
+    if untouched > 0:                                      # utils.py:100-104
+        if not matrix.is_contiguous():
+            raise L.DirHipError("calibrate_mean_var: the in-place branch (some v1 == 0) needs a contiguous matrix")
+        return _CalibrateFn.apply(matrix, m1, m2, scale, True)
+    return _CalibrateFn.apply(matrix, m1, m2, scale, False)
 
 
 def get_lds_kernel_window(kernel, ks, sigma):

@@ -161,7 +161,13 @@ def test_calibrate_mean_var_function(golden):
     for i in range(int(g["n"])):
         lo, hi = (float(v) for v in g[f"clip_{i}"])
         x = dev(g[f"in_x_{i}"]).requires_grad_(True)
-        y = calibrate_mean_var(x, dev(g[f"in_m1_{i}"]), dev(g[f"in_v1_{i}"]), dev(g[f"in_m2_{i}"]), dev(g[f"in_v2_{i}"]), lo, hi)
+        xin = x.clone()                                            # (a non-leaf: two of the reference's three branches return / modify the input object)
+        y = calibrate_mean_var(xin, dev(g[f"in_m1_{i}"]), dev(g[f"in_v1_{i}"]), dev(g[f"in_m2_{i}"]), dev(g[f"in_v2_{i}"]), lo, hi)
+        v1 = g[f"in_v1_{i}"]
+        if np.sum(v1, dtype=np.float32) < 1e-10 or (v1 == 0).any():
+            assert y is xin, f"case {i}: utils.py:98-104 return the input object (calibrated in place where some v1 == 0)"
+        else:
+            assert y is not xin and y.data_ptr() != xin.data_ptr() and np.array_equal(xin.detach().cpu().numpy(), g[f"in_x_{i}"]), f"case {i}: utils.py:106-107 is out of place"
         assert_close(y.detach().cpu().numpy(), g[f"ref_y_{i}"], rtol=2e-7, atol_scale=2e-7, msg=f"case {i}")
         yo = fds_oracle.calibrate_mean_var(g[f"in_x_{i}"].copy(), g[f"in_m1_{i}"], g[f"in_v1_{i}"], g[f"in_m2_{i}"], g[f"in_v2_{i}"], lo, hi)
         assert np.array_equal(y.detach().cpu().numpy(), yo)
