@@ -64,6 +64,19 @@ def test_train_py_cli_train_resume_evaluate(tmp_path):
     assert "testing..." in out and "Test: " in out and " * Low: MSE" in out
 
 
+def test_train_py_cli_precision_schedule(tmp_path):
+    """train.py --amp_switch_epoch 1 (round 6): epoch 0 on the float32 conv stack, epoch 1 in bf16, one engine; a resume at epoch 1 starts in bf16."""
+    base = ["--synthetic", "512", "--fds", "--lds", "--reweight", "sqrt_inv", "--batch_size", "64", "--store_root", str(tmp_path), "--print_freq", "4",
+            "--amp_switch_epoch", "1"]
+    out = _cli(base + ["--epoch", "2"], "cli_amp_switch.log")
+    assert "Epoch [0]: conv stack in float32 (--amp_switch_epoch 1)" in out and "Epoch [1]: conv stack in bf16 (--amp_switch_epoch 1)" in out, out[-2000:]
+    assert "Epoch #1: Train loss" in out and "Test loss: MSE" in out
+    store = [d for d in os.listdir(tmp_path) if (tmp_path / d / "ckpt.pth.tar").is_file()]
+    assert len(store) == 1
+    out = _cli(base + ["--epoch", "3", "--resume", str(tmp_path / store[0] / "ckpt.pth.tar")], "cli_amp_switch_resume.log")
+    assert "conv stack in float32" not in out and "Epoch [2]: conv stack in bf16" in out and "Epoch #2: Train loss" in out, out[-2000:]
+
+
 def test_train_py_cli_on_image_files_host_and_gpu_augment(tmp_path):
     """The real-data path of the drop-in CLI, executed: an agedb-style csv + image files (written here), DataLoader workers, the
     host transform chain — the same run with --gpu_augment (uint8 batches, dir_augment_u8 on the GPU) — and with
