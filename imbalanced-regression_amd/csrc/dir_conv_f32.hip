@@ -230,7 +230,9 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_wgrad_reduce_kernel(const fl
 // stay on the gather kernels.
 constexpr int FT_BK = 16, FT_ROWB = FT_BK * 4;
 constexpr int FT_OOB = (int)0x80000000;
-constexpr int FT_ABLATE = 0;            // measurement builds only (tools/ablate_f32.py patches this line): 1 = no DMA, 2 = no epilogue stores, 3 = no MFMA, 4 = no barriers / DMA waits
+constexpr int FT_SPLIT_STAGES = 2;      // ring depth of the split-bf16 arithmetics: a K-step of 16 is ~0.2 us of their matrix work, less than one L2 round trip,
+                                        // so FT_SPLIT_STAGES - 1 K-steps stay in flight (counted s_waitcnt, one barrier per K-step)
+constexpr int FT_ABLATE = 0;            // measurement builds only (tools/ablate_f32.py patches this line): 1 = no DMA, 2 = no epilogue stores, 3 = no MFMA, 4 = no barriers / DMA waits, 5 = (split arithmetics) no split VALU work
 enum { FT_FWD = 0, FT_DGRAD = 1, FT_WGRAD = 2 };
 
 struct ConvF32T {
@@ -244,15 +246,57 @@ struct ConvF32T {
 };
 
 
-template <int TM, int TN, int MODE>
-__global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
+// ARITH (round 6): 0 = v_mfma_f32_32x32x2_f32 on the float32 operands (exact: the parity arithmetic); 3 / 2 = SPLIT-bf16 arithmetic on the bf16 matrix
+// pipe: every float32 operand element is split in registers into three (two) bf16 terms hi + mid (+ lo) — each split exact: the residual of a
+// round-to-nearest bf16 is representable in float32 — and a K-step of 16 becomes ONE v_mfma_f32_32x32x16_bf16 per term pair kept: hi*hi, hi*mid,
+// mid*hi, hi*lo, lo*hi, mid*mid (ARITH 3: the dropped pairs are below 2^-24 of the product: float32-GRADE results, not bit-equal ones) or hi*hi,
+// hi*lo, lo*hi (ARITH 2, terms hi + lo: 16 significand bits). 6 (3) x 32 matrix clocks per 32 x 32 x 16 block instead of 8 x 64; the price is
+// ~44 (24) VALU operations per 8-element fragment for the splits. Same staging, same epilogue, same statistics rows as the exact kernel.
+typedef __attribute__((ext_vector_type(8))) float cf_f32x8;
+typedef __attribute__((ext_vector_type(4))) float cf_f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
+// Cost of the split per element (measured forms, profiles/r06_f32_split_arith.txt): a v_cvt_pk_bf16_f32 rounds two elements to nearest, the residual needs
+// the rounded value back as float32 (shift / mask of the packed pair) and one exact subtraction. THREE terms: the two leading terms are TRUNCATED instead
+// (upper 16 bits: one v_perm_b32 packs a pair, v_and + v_sub leave the exact residual) and only the last term is rounded — the error of the sum of the
+// terms is that of the last rounding, 2^-24 of the element, unbiased; 0.5 instead of 1.5 conversions per element. TWO terms: both rounded to nearest
+// (truncating the leading term doubles the error, 2^-16 instead of 2^-17, for 3 % of the time).
+constexpr int FT_X2_WAVES = 4;         // wavefronts per SIMD the two-term kernels are compiled for (their natural allocation is 130-147 registers = 3)
+constexpr int FT_WAVES(int arith) { return arith == 2 ? FT_X2_WAVES : (arith == 3 ? 3 : 4); }
+constexpr bool FT_SPLIT_RNE_HI(int nt) { return nt == 2; }
+template <int NT>
+__device__ __forceinline__ void ft_split(cf_f32x8 v, cf_bf16x8 (&t)[NT]) {
+    typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#pragma unroll
+    for (int s = 0; s + 1 < NT; ++s) {
+        u32x4 pk;
+        u32x8 hb;
+        if (FT_SPLIT_RNE_HI(NT)) {
+            pk = __builtin_bit_cast(u32x4, __builtin_convertvector(v, cf_bf16x8));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hb[2 * j] = pk[j] << 16; hb[2 * j + 1] = pk[j] & 0xffff0000u; }
+        } else {
+            const u32x8 b = __builtin_bit_cast(u32x8, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk[j] = __builtin_amdgcn_perm(b[2 * j + 1], b[2 * j], 0x07060302u);
+            hb = b & 0xffff0000u;
+        }
+        t[s] = __builtin_bit_cast(cf_bf16x8, pk);
+        v -= __builtin_bit_cast(cf_f32x8, hb);                               // exact
+    }
+    t[NT - 1] = __builtin_convertvector(v, cf_bf16x8);                       // v_cvt_pk_bf16_f32: round to nearest even
+}
+
+template <int TM, int TN, int MODE, int ARITH = 0>
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT_WAVES(ARITH)))) conv_f32_tile_kernel(ConvF32T q) {
     const ConvF32P& p = q.c;
     constexpr bool AKM = MODE == FT_WGRAD, BKM = MODE != FT_FWD;
     constexpr int WGM = (TM == 128 && TN == 64) ? 4 : 2, WGN = 4 / WGM;
     constexpr int WM = TM / WGM, WN = TN / WGN, MI = WM / 32, NI = WN / 32;
     constexpr int NA = TM / 64, NB = TN / 64;                       // 1 KB DMA pieces per wavefront and K-step
     constexpr int A_BYTES = TM * FT_ROWB, STAGE = (TM + TN) * FT_ROWB;
-    constexpr int LDS_BYTES = (2 * STAGE > 64 * TN * 4) ? 2 * STAGE : 64 * TN * 4;     // two K-loop stages; the epilogue's 64-row slab
+    constexpr int NS = ARITH ? FT_SPLIT_STAGES : 2;                 // LDS stages: two for the exact arithmetic (bound by the matrix pipe), a ring for the split ones
+    constexpr int LDS_BYTES = (NS * STAGE > 64 * TN * 4) ? NS * STAGE : 64 * TN * 4;   // the K-loop stages; the epilogue's 64-row slab
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     int lin;
     {
@@ -452,20 +496,94 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_tile_kernel(ConvF32T q) {
         }
     };
 
-    int stage = 0;
-    if (nsteps > 0) {
-        issue(0, kbeg);
-        cp_dma_wait();
-        __syncthreads();
-        for (int it = 0; it < nsteps; ++it) {
-            if (it + 1 < nsteps) issue(stage ^ 1, kbeg + (it + 1) * FT_BK);    // next K-step in flight under this one's MFMAs
-            mfma_step(stage);
-            if (FT_ABLATE != 4) {
-                cp_dma_wait();                                      // this wavefront's pieces of the next stage have landed ...
-                __syncthreads();                                    // ... everyone's have, and everyone is done reading this stage
+    // Split-bf16 K-step (ARITH 2 / 3): lane (fi, fh) takes the EIGHT k = 8 fh .. 8 fh + 7 of its row (K-contiguous tiles: two ds_read_b128, the
+    // chunks 2 fh and 2 fh + 1; k-major tiles: eight ds_read_b32) as element i of the bf16 fragments — the same k <-> element map for both operands.
+    // Term pairs in ascending magnitude, the four accumulator tiles interleaved (no two consecutive MFMAs on one accumulator).
+    auto mfma_step_split = [&](int stage) {
+        constexpr int NT = ARITH == 3 ? 3 : 2;
+        const unsigned char* sbase = smem + stage * STAGE;
+        cf_bf16x8 at[MI][NT], bt[NI][NT];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            cf_f32x8 v;
+            if (!AKM) {
+                const float4 lo4 = *reinterpret_cast<const float4*>(sbase + afo[mi] + (((uint32_t)(2 * fh) ^ aswz) << 4));
+                const float4 hi4 = *reinterpret_cast<const float4*>(sbase + afo[mi] + (((uint32_t)(2 * fh + 1) ^ aswz) << 4));
+                v = (cf_f32x8){lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            } else {
+                // afo = fh * TM * 4 + row * 4 (the exact kernel's k = 2 j + fh rows): here rows k = 8 fh + i
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float*>(sbase + afo[mi] + (7 * fh + i) * (TM * 4));
             }
-            stage ^= 1;
+            if (FT_ABLATE == 5) { for (int s_ = 0; s_ < NT; ++s_) at[mi][s_] = __builtin_bit_cast(cf_bf16x8, (cf_f32x4){v[s_], v[s_ + 1], v[s_ + 2], v[s_ + 3]}); }
+            else ft_split<NT>(v, at[mi]);
         }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            cf_f32x8 v;
+            if (!BKM) {
+                const float4 lo4 = *reinterpret_cast<const float4*>(sbase + bfo[ni] + (((uint32_t)(2 * fh) ^ bswz) << 4));
+                const float4 hi4 = *reinterpret_cast<const float4*>(sbase + bfo[ni] + (((uint32_t)(2 * fh + 1) ^ bswz) << 4));
+                v = (cf_f32x8){lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float*>(sbase + bfo[ni] + (7 * fh + i) * (TN * 4));
+            }
+            if (FT_ABLATE == 5) { for (int s_ = 0; s_ < NT; ++s_) bt[ni][s_] = __builtin_bit_cast(cf_bf16x8, (cf_f32x4){v[s_], v[s_ + 1], v[s_ + 2], v[s_ + 3]}); }
+            else ft_split<NT>(v, bt[ni]);
+        }
+        // (term of A, term of B), smallest products first; index NT - 1 = lo, 0 = hi
+        constexpr int NP = ARITH == 3 ? 6 : 3;
+        constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+            const int ta = ARITH == 3 ? PA3[pi] : PA2[pi], tb = ARITH == 3 ? PB3[pi] : PB2[pi];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    if (FT_ABLATE == 3) asm volatile("" :: "v"(at[mi][ta]), "v"(bt[ni][tb]));
+                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[mi][ta], bt[ni][tb], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    int stage = 0;
+    if (ARITH == 0) {
+        if (nsteps > 0) {
+            issue(0, kbeg);
+            cp_dma_wait();
+            __syncthreads();
+            for (int it = 0; it < nsteps; ++it) {
+                if (it + 1 < nsteps) issue(stage ^ 1, kbeg + (it + 1) * FT_BK);    // next K-step in flight under this one's MFMAs
+                mfma_step(stage);
+                if (FT_ABLATE != 4) {
+                    cp_dma_wait();                                      // this wavefront's pieces of the next stage have landed ...
+                    __syncthreads();                                    // ... everyone's have, and everyone is done reading this stage
+                }
+                stage ^= 1;
+            }
+        }
+    } else {
+        // ring of NS stages, NS - 1 K-steps in flight: the wavefront's pieces land in issue order, so "all but the youngest (NS - 2) K-steps' pieces"
+        // = s_waitcnt vmcnt((NS - 2) * (NA + NB)); the barrier then says everyone's pieces of this stage have landed AND everyone has finished reading the
+        // stage of the previous K-step, which is the one the next issue overwrites
+        constexpr int PF = NS - 1, PIECES = NA + NB;
+        for (int s_ = 0; s_ < PF && s_ < nsteps; ++s_) issue(s_, kbeg + s_ * FT_BK);
+        int nxt = PF % NS;                                              // stage of the next issue
+        for (int it = 0; it < nsteps; ++it) {
+            const int younger = nsteps - 1 - it;                        // K-steps issued after this one (capped at PF - 1 by the ring)
+            if (FT_ABLATE != 4) {
+                if (younger >= PF - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PF - 1) * PIECES) : "memory");
+                else if (PF >= 3 && younger == PF - 2 && PF - 2 > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PF >= 3 ? PF - 2 : 0) * PIECES) : "memory");
+                else cp_dma_wait();
+                __syncthreads();
+            }
+            if (it + PF < nsteps) { issue(nxt, kbeg + (it + PF) * FT_BK); nxt = nxt + 1 == NS ? 0 : nxt + 1; }
+            mfma_step_split(stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+        __syncthreads();                                                // the epilogue reuses the stages' LDS
     }
 
     // ---- store. C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds ONE column, so
@@ -598,14 +716,20 @@ int ft_wgrad_splits(int M, int Ncol, int K, int TM, int TN, int* klen) {
 }
 void ft_wgrad_tile(const ConvF32P& p, int* TM, int* TN) { *TM = p.M >= 128 ? 128 : 64; *TN = p.Ncol >= 128 ? 128 : 64; }
 
+// arith: 0 = exact float32 MFMA, 3 / 2 = split-bf16 with three / two terms per operand (the kernel's ARITH)
 template <int TM, int TN, int MODE>
-int ft_launch(ConvF32T q, int splits, hipStream_t s) {
+int ft_launch(ConvF32T q, int splits, hipStream_t s, int arith = 0) {
     q.ntn = dir_cdiv(q.c.Ncol, TN);
     q.nblocks = dir_cdiv(q.c.M, TM) * q.ntn;
-    hipLaunchKernelGGL((conv_f32_tile_kernel<TM, TN, MODE>), dim3(q.nblocks, splits), dim3(DIR_TPB), 0, s, q);
+    if (arith == 3) hipLaunchKernelGGL((conv_f32_tile_kernel<TM, TN, MODE, 3>), dim3(q.nblocks, splits), dim3(DIR_TPB), 0, s, q);
+    else if (arith == 2) hipLaunchKernelGGL((conv_f32_tile_kernel<TM, TN, MODE, 2>), dim3(q.nblocks, splits), dim3(DIR_TPB), 0, s, q);
+    else hipLaunchKernelGGL((conv_f32_tile_kernel<TM, TN, MODE, 0>), dim3(q.nblocks, splits), dim3(DIR_TPB), 0, s, q);
     DIR_LAUNCH_CHECK();
     return DIR_OK;
 }
+// `variant` of the C-ABI -> (kernel family, arithmetic): the split forms are tile kernels
+inline int ft_arith(int variant) { return variant == DIR_CONV_F32_TILE_X3 ? 3 : (variant == DIR_CONV_F32_TILE_X2 ? 2 : 0); }
+inline bool ft_forced_tile(int variant) { return variant >= DIR_CONV_F32_TILE; }
 
 int cf_check(const void* a, const void* b, const void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
              int* Ho, int* Wo) {
@@ -655,7 +779,7 @@ static int cf_fwd_impl(const float* x, const float* w, float* y, float* stats, i
     int Ho, Wo;
     const int rc = cf_check(x, w, y, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
-    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE_X2, DIR_EINVAL);
     ConvF32P p;
     p.a = x; p.b = w; p.out = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
@@ -663,7 +787,7 @@ static int cf_fwd_impl(const float* x, const float* w, float* y, float* stats, i
     p.addend = p.addend2 = p.mask = nullptr; p.stats = nullptr;
     const size_t xe = (size_t)N * H * W * Cin, we = (size_t)Cout * p.K;
     const bool tile_ok = dir_aligned16(x) && dir_aligned16(w) && ft_ok(FT_FWD, p, xe, we);
-    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(ft_forced_tile(variant) && !tile_ok, DIR_EUNSUPPORTED);
     if (stats) {                                                        // fused BatchNorm statistics: tile kernel + its LDS store loop only
         DIR_RETURN_IF(!tile_ok || variant == DIR_CONV_F32_GATHER || (Cout & 3), DIR_EUNSUPPORTED);
         DIR_RETURN_IF((size_t)stats_rows != dir_conv_f32_stats_rows(N, Ho, Wo), DIR_EINVAL);
@@ -671,7 +795,7 @@ static int cf_fwd_impl(const float* x, const float* w, float* y, float* stats, i
     }
     if (tile_ok && variant != DIR_CONV_F32_GATHER) {
         const ConvF32T q = ft_params(p, xe, we);
-        return p.Ncol > 64 ? ft_launch<128, 128, FT_FWD>(q, 1, dir_s(stream)) : ft_launch<128, 64, FT_FWD>(q, 1, dir_s(stream));
+        return p.Ncol > 64 ? ft_launch<128, 128, FT_FWD>(q, 1, dir_s(stream), ft_arith(variant)) : ft_launch<128, 64, FT_FWD>(q, 1, dir_s(stream), ft_arith(variant));
     }
     DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535, DIR_EUNSUPPORTED);
     hipLaunchKernelGGL((conv_f32_kfast_kernel<0>), dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN)), dim3(DIR_TPB), 0, dir_s(stream), p);
@@ -697,13 +821,19 @@ extern "C" int dir_conv_f32_fwd_stats(const float* x, const float* w, float* y, 
     return cf_fwd_impl(x, w, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, 0, stream);
 }
 
+extern "C" int dir_conv_f32_fwd_stats_variant(const float* x, const float* w, float* y, float* stats, int stats_rows, int N, int H, int W, int Cin,
+                                              int Cout, int R, int S, int stride, int pad, int variant, dir_stream_t stream) {
+    DIR_RETURN_IF(!stats, DIR_EINVAL);
+    return cf_fwd_impl(x, w, y, stats, stats_rows, N, H, W, Cin, Cout, R, S, stride, pad, variant, stream);
+}
+
 extern "C" int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
                                           const float* relu_mask, float* dx, int N, int H, int W, int Cin, int Cout, int R, int S,
                                           int stride, int pad, int variant, dir_stream_t stream) {
     int Ho, Wo;
     const int rc = cf_check(dy, w, dx, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
-    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE_X2, DIR_EINVAL);
     DIR_RETURN_IF(addend_s2 && ((H | W) & 1), DIR_EUNSUPPORTED);
     ConvF32P p;
     p.a = dy; p.b = w; p.out = dx;
@@ -712,12 +842,12 @@ extern "C" int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const
     p.addend = addend; p.addend2 = addend_s2; p.mask = relu_mask; p.stats = nullptr;
     const size_t ye = (size_t)N * Ho * Wo * Cout, we = (size_t)Cout * R * S * Cin;
     const bool tile_ok = dir_aligned16(dy) && dir_aligned16(w) && ft_ok(FT_DGRAD, p, ye, we);
-    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile_ok, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(ft_forced_tile(variant) && !tile_ok, DIR_EUNSUPPORTED);
     if (tile_ok && variant != DIR_CONV_F32_GATHER) {
         ConvF32T q = ft_params(p, ye, we);
         int zdim = 1;
         if (stride == 2 && !((H | W) & 1)) { q.cls = 1; q.c.M = N * (H >> 1) * (W >> 1); zdim = 4; }     // four parity classes, only their own filter taps
-        return p.Ncol > 64 ? ft_launch<128, 128, FT_DGRAD>(q, zdim, dir_s(stream)) : ft_launch<128, 64, FT_DGRAD>(q, zdim, dir_s(stream));
+        return p.Ncol > 64 ? ft_launch<128, 128, FT_DGRAD>(q, zdim, dir_s(stream), ft_arith(variant)) : ft_launch<128, 64, FT_DGRAD>(q, zdim, dir_s(stream), ft_arith(variant));
     }
     DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535, DIR_EUNSUPPORTED);
     hipLaunchKernelGGL((conv_f32_kfast_kernel<1>), dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN)), dim3(DIR_TPB), 0, dir_s(stream), p);
@@ -767,17 +897,17 @@ extern "C" int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float
     int Ho, Wo;
     const int rc = cf_check(dy, x, dw, N, H, W, Cin, Cout, R, S, stride, pad, &Ho, &Wo);
     if (rc != DIR_OK) return rc;
-    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE, DIR_EINVAL);
+    DIR_RETURN_IF(variant < 0 || variant > DIR_CONV_F32_TILE_X2, DIR_EINVAL);
     ConvF32P p;
     int splits, TM = 64, TN = 64;
     bool tile = cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, variant, &p, &splits, &TM, &TN);
     p.a = dy; p.b = x;
     if (tile && !(dir_aligned16(dy) && dir_aligned16(x))) {
-        DIR_RETURN_IF(variant == DIR_CONV_F32_TILE, DIR_EUNSUPPORTED);
+        DIR_RETURN_IF(ft_forced_tile(variant), DIR_EUNSUPPORTED);
         tile = cf_wgrad_plan(N, H, W, Cin, Cout, R, S, stride, pad, DIR_CONV_F32_GATHER, &p, &splits, &TM, &TN);
         p.a = dy; p.b = x;
     }
-    DIR_RETURN_IF(variant == DIR_CONV_F32_TILE && !tile, DIR_EUNSUPPORTED);
+    DIR_RETURN_IF(ft_forced_tile(variant) && !tile, DIR_EUNSUPPORTED);
     const size_t need = dir_align_up((size_t)splits * Cout * R * S * Cin * sizeof(float), 256);
     DIR_RETURN_IF(splits > 1 && (!workspace || workspace_bytes < need), DIR_EWORKSPACE);
     DIR_RETURN_IF(dir_cdiv(p.Ncol, CF_BN) > 65535 || splits > 65535, DIR_EUNSUPPORTED);
@@ -785,8 +915,9 @@ extern "C" int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float
     if (tile) {
         const ConvF32T q = ft_params(p, (size_t)p.K * Cout, (size_t)N * H * W * Cin);
         int rc2;
-        if (TM == 128) rc2 = TN == 128 ? ft_launch<128, 128, FT_WGRAD>(q, splits, dir_s(stream)) : ft_launch<128, 64, FT_WGRAD>(q, splits, dir_s(stream));
-        else rc2 = TN == 128 ? ft_launch<64, 128, FT_WGRAD>(q, splits, dir_s(stream)) : ft_launch<64, 64, FT_WGRAD>(q, splits, dir_s(stream));
+        const int ar = ft_arith(variant);
+        if (TM == 128) rc2 = TN == 128 ? ft_launch<128, 128, FT_WGRAD>(q, splits, dir_s(stream), ar) : ft_launch<128, 64, FT_WGRAD>(q, splits, dir_s(stream), ar);
+        else rc2 = TN == 128 ? ft_launch<64, 128, FT_WGRAD>(q, splits, dir_s(stream), ar) : ft_launch<64, 64, FT_WGRAD>(q, splits, dir_s(stream), ar);
         if (rc2 != DIR_OK) return rc2;
     } else {
         hipLaunchKernelGGL(conv_f32_wgrad_kernel, dim3(dir_cdiv(p.M, CF_BM), dir_cdiv(p.Ncol, CF_BN), splits), dim3(DIR_TPB), 0, dir_s(stream), p);

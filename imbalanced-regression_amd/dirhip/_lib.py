@@ -121,6 +121,7 @@ SIGNATURES = {
     "dir_conv_f32_fwd_variant": (c_int, [c_void_p] * 3 + [c_int] * 10 + [c_void_p]),
     "dir_conv_f32_stats_rows": (c_size_t, [c_int] * 3),
     "dir_conv_f32_fwd_stats": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dir_conv_f32_fwd_stats_variant": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     "dir_conv_f32_dgrad_variant": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "dir_conv_f32_wgrad_variant": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_int, c_void_p]),
     "dir_maxpool3x3s2_f32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -133,7 +134,7 @@ SIGNATURES = {
     "dir_lds_weights": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DIR_F32, DIR_BF16 = 0, 1
 WGRAD_AUTO, WGRAD_TRANSPOSE, WGRAD_DMA1, WGRAD_DMA2 = 0, 1, 2, 3                             # DIR_WGRAD_*
 CONV_AUTO, CONV_TILE_REG, CONV_TILE_DMA, CONV_PATCH3, CONV_BIG = 0, 1, 2, 3, 5      # DIR_CONV_* of include/dir_hip.h

@@ -9,6 +9,9 @@ north_star's 1e-5 loss bar. The bf16 path also lands here (through float32 casts
 take — channel counts that are not multiples of 64, strided data gradients of odd-sized maps, tensors beyond 32-bit
 offsets — so that no library convolution is ever called.
 """
+import contextlib
+import threading
+
 import torch
 
 from . import _lib as L
@@ -23,6 +26,37 @@ def _f32(t):
 
 
 GATHER, TILE = 1, 2                     # DIR_CONV_F32_GATHER / DIR_CONV_F32_TILE: force a kernel (0 = the product's choice: tile where applicable)
+TILE_X3, TILE_X2 = 3, 4                 # DIR_CONV_F32_TILE_X3 / _X2: the tile kernels with split-bf16 arithmetic (float32-GRADE, not bit-equal; ABI 4)
+ARITHMETICS = {"exact": 0, "x3": TILE_X3, "x2": TILE_X2}
+
+# The arithmetic of the float32 graph nodes is a property of the FORWARD PASS that builds them (set by the engine for the span of one forward call,
+# `DataParallelEngine(f32_arith=...)` / `train.py --amp fp32x3`), recorded in each node and used again by its backward: thread-local, no process-wide switch.
+_SCOPE = threading.local()
+
+
+def current_arith():
+    """``variant`` code of the float32 convolutions built now: 0 (exact float32 MFMA), ``TILE_X3`` or ``TILE_X2``."""
+    return getattr(_SCOPE, "variant", 0)
+
+
+@contextlib.contextmanager
+def arithmetic(name):
+    """``with arithmetic("x3"):`` — float32 convolution nodes created inside run (forward AND backward) on the split-bf16 kernels wherever the tile
+    kernels take the geometry (whole 16-channel K-steps; the 7x7 stem and odd shapes stay exact). ``"exact"`` / None: the parity arithmetic."""
+    prev = current_arith()
+    _SCOPE.variant = ARITHMETICS[name or "exact"]
+    try:
+        yield
+    finally:
+        _SCOPE.variant = prev
+
+
+def _checked(fn_name, rc_of, variant):
+    """Run ``rc_of(variant)``; a split arithmetic on a geometry the tile kernels do not take (DIR_EUNSUPPORTED) falls back to the product's exact choice."""
+    rc = rc_of(variant)
+    if rc == L.DIR_EUNSUPPORTED and variant in (TILE_X3, TILE_X2):
+        rc = rc_of(0)
+    L.check(rc, fn_name)
 
 
 def stats_fusable(x, w):
@@ -42,17 +76,17 @@ def conv2d_f32_fwd(x, w, stride, padding, variant=0, want_stats=False):
     wo = (wd + 2 * padding - s) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if want_stats:
-        if variant != 0 or not stats_fusable(x, w):
+        if variant in (GATHER, TILE) or not stats_fusable(x, w):
             return conv2d_f32_fwd(x, w, stride, padding, variant), None
         rows = L.lib().dir_conv_f32_stats_rows(n, ho, wo)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            L.check(L.lib().dir_conv_f32_fwd_stats(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), rows, n, h, wd, cin, cout, r, s, stride, padding,
-                                                   L.stream_ptr(x.device)), "dir_conv_f32_fwd_stats")
+            _checked("dir_conv_f32_fwd_stats", lambda v: L.lib().dir_conv_f32_fwd_stats_variant(
+                L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(stats), rows, n, h, wd, cin, cout, r, s, stride, padding, v, L.stream_ptr(x.device)), variant)
         return y, stats
     with torch.cuda.device(x.device):
-        L.check(L.lib().dir_conv_f32_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, cin, cout, r, s, stride, padding, variant,
-                                                 L.stream_ptr(x.device)), "dir_conv_f32_fwd")
+        _checked("dir_conv_f32_fwd", lambda v: L.lib().dir_conv_f32_fwd_variant(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, cin, cout, r, s, stride, padding, v,
+                                                                             L.stream_ptr(x.device)), variant)
     return y
 
 
@@ -67,9 +101,9 @@ def conv2d_f32_dgrad(dy, w, in_hw, stride, padding, addend=None, addend_s2=None,
     for t, shp in ((addend, (n, cin, h, wd)), (relu_mask, (n, cin, h, wd)), (addend_s2, (n, cin, h // 2, wd // 2))):
         assert t is None or (tuple(t.shape) == shp and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)), shp
     with torch.cuda.device(dy.device):
-        L.check(L.lib().dir_conv_f32_dgrad_variant(L.ptr(dy), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(dx),
-                                                   n, h, wd, cin, cout, r, s, stride, padding, variant, L.stream_ptr(dy.device)),
-                "dir_conv_f32_dgrad")
+        _checked("dir_conv_f32_dgrad", lambda v: L.lib().dir_conv_f32_dgrad_variant(
+            L.ptr(dy), L.ptr(w), L.ptr(addend), L.ptr(addend_s2), L.ptr(relu_mask), L.ptr(dx), n, h, wd, cin, cout, r, s, stride, padding, v,
+            L.stream_ptr(dy.device)), variant)
     return dx
 
 
@@ -83,8 +117,8 @@ def conv2d_f32_wgrad(dy, x, kernel_hw, stride, padding, variant=0):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = torch.empty((cout, cin, r, s), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        L.check(L.lib().dir_conv_f32_wgrad_variant(L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, wd, cin, cout, r, s, stride, padding, L.ptr(ws),
-                                                   ws.numel(), variant, L.stream_ptr(x.device)), "dir_conv_f32_wgrad")
+        _checked("dir_conv_f32_wgrad", lambda v: L.lib().dir_conv_f32_wgrad_variant(
+            L.ptr(dy), L.ptr(x), L.ptr(dw), n, h, wd, cin, cout, r, s, stride, padding, L.ptr(ws), ws.numel(), v, L.stream_ptr(x.device)), variant)
     return dw
 
 
@@ -99,7 +133,8 @@ class _ConvF32Fn(torch.autograd.Function):
         ctx.in_dtype = x.dtype
         ctx.stride, ctx.padding = stride, padding
         x32, w32 = _nhwc(_f32(x)), _nhwc(_f32(weight.detach()))
-        y = conv2d_f32_fwd(x32, w32, stride, padding)
+        ctx.variant = current_arith()
+        y = conv2d_f32_fwd(x32, w32, stride, padding, variant=ctx.variant)
         ctx.save_for_backward(x32, w32)
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
@@ -109,10 +144,10 @@ class _ConvF32Fn(torch.autograd.Function):
         dy32 = _nhwc(_f32(dy))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_f32_dgrad(dy32, w32, x32.shape[2:], ctx.stride, ctx.padding)
+            dx = conv2d_f32_dgrad(dy32, w32, x32.shape[2:], ctx.stride, ctx.padding, variant=ctx.variant)
             if ctx.in_dtype != torch.float32:
                 dx = dx.to(ctx.in_dtype)
-        dw = conv2d_f32_wgrad(dy32, x32, w32.shape[2:], ctx.stride, ctx.padding) if ctx.needs_input_grad[1] else None
+        dw = conv2d_f32_wgrad(dy32, x32, w32.shape[2:], ctx.stride, ctx.padding, variant=ctx.variant) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None
 
 
@@ -194,7 +229,8 @@ class _ConvGraphF32Fn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.stride, ctx.padding, ctx.relu_input = stride, padding, relu_input
         x32, w32 = _nhwc(x), _nhwc(weight.detach())
-        y, stats = conv2d_f32_fwd(x32, w32, stride, padding, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w32, stride, padding), None)
+        v = ctx.variant = current_arith()
+        y, stats = conv2d_f32_fwd(x32, w32, stride, padding, v, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w32, stride, padding, v), None)
         ctx.save_for_backward(x32, w32)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -211,10 +247,10 @@ class _ConvGraphF32Fn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv2d_f32_dgrad(dy, w32, x.shape[2:], ctx.stride, ctx.padding, addend=dalias,
-                                  relu_mask=x if ctx.relu_input else None)
+                                  relu_mask=x if ctx.relu_input else None, variant=ctx.variant)
         elif dalias is not None:
             dx = dalias
-        dw = conv2d_f32_wgrad(dy, x, w32.shape[2:], ctx.stride, ctx.padding)
+        dw = conv2d_f32_wgrad(dy, x, w32.shape[2:], ctx.stride, ctx.padding, variant=ctx.variant)
         return dx, dw, None, None, None, None, None
 
 
@@ -229,8 +265,9 @@ class _ProjectionPairF32Fn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.stride_d, ctx.relu_input = stride_d, relu_input
         x32, w1_32, wd_32 = _nhwc(x), _nhwc(w1.detach()), _nhwc(wd.detach())
-        y1, s1 = conv2d_f32_fwd(x32, w1_32, 1, 0, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w1_32, 1, 0), None)
-        yd, sd = conv2d_f32_fwd(x32, wd_32, stride_d, 0, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, wd_32, stride_d, 0), None)
+        v = ctx.variant = current_arith()
+        y1, s1 = conv2d_f32_fwd(x32, w1_32, 1, 0, v, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, w1_32, 1, 0, v), None)
+        yd, sd = conv2d_f32_fwd(x32, wd_32, stride_d, 0, v, want_stats=True) if want_stats else (conv2d_f32_fwd(x32, wd_32, stride_d, 0, v), None)
         ctx.save_for_backward(x32, w1_32, wd_32)
         for st in (s1, sd):
             if st is not None:
@@ -246,15 +283,16 @@ class _ProjectionPairF32Fn(torch.autograd.Function):
         dyd = None if dyd is None else _nhwc(_f32(dyd))
         mask = x if ctx.relu_input else None
         # the downsample conv's data gradient in COMPACT form: a plain 1x1 stride-1 data gradient on its own dY grid
-        compact = conv2d_f32_dgrad(dyd, wd, dyd.shape[2:], 1, 0) if dyd is not None else None
+        v = ctx.variant
+        compact = conv2d_f32_dgrad(dyd, wd, dyd.shape[2:], 1, 0, variant=v) if dyd is not None else None
         if compact is None:
-            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, relu_mask=mask)
+            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, relu_mask=mask, variant=v)
         elif ctx.stride_d == 1:
-            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, addend=compact, relu_mask=mask)
+            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, addend=compact, relu_mask=mask, variant=v)
         else:
-            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, addend_s2=compact, relu_mask=mask)
-        dw1 = conv2d_f32_wgrad(dy1, x, (1, 1), 1, 0)
-        dwd = conv2d_f32_wgrad(dyd, x, (1, 1), ctx.stride_d, 0) if dyd is not None else None
+            dx = conv2d_f32_dgrad(dy1, w1, x.shape[2:], 1, 0, addend_s2=compact, relu_mask=mask, variant=v)
+        dw1 = conv2d_f32_wgrad(dy1, x, (1, 1), 1, 0, variant=v)
+        dwd = conv2d_f32_wgrad(dyd, x, (1, 1), ctx.stride_d, 0, variant=v) if dyd is not None else None
         return (dx if ctx.needs_input_grad[0] else None), dw1, dwd, None, None, None
 
 

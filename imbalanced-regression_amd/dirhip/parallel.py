@@ -93,7 +93,7 @@ class DataParallelEngine(nn.Module):
     the gradient exchange is driven by autograd hooks and completes before ``backward()`` returns."""
 
     def __init__(self, module, process_group=None, bucket_mb=32, amp_dtype=None, channels_last=False,
-                 broadcast_from_rank0=True, force_collectives=False):
+                 broadcast_from_rank0=True, force_collectives=False, f32_arith="exact"):
         super().__init__()
         self.module = module
         self.process_group = process_group
@@ -114,6 +114,10 @@ class DataParallelEngine(nn.Module):
             weakref.finalize(self, _release_collectives_guard)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.amp_dtype = amp_dtype
+        # arithmetic of the float32 conv stack (amp_dtype None): "exact" = v_mfma_f32_32x32x2_f32, the parity mode; "x3" / "x2" = split-bf16 on the
+        # bf16 matrix pipe, float32-grade and 1.4x / 2x faster (conv_f32.arithmetic; `train.py --amp fp32x3`)
+        assert f32_arith in ("exact", "x3", "x2"), f32_arith
+        self.f32_arith = f32_arith
         self.channels_last = channels_last
         self._buckets = None
         self._bucket_of = {}
@@ -145,12 +149,15 @@ class DataParallelEngine(nn.Module):
             if force_collectives:
                 fds.force_collectives = True
 
-    def set_amp_dtype(self, amp_dtype):
+    def set_amp_dtype(self, amp_dtype, f32_arith=None):
         """Switch the conv stack's arithmetic between runs of the SAME graph: ``torch.bfloat16`` (bf16 MFMA kernels under autocast) or None
-        (exact-float32 MFMA kernels). Takes effect at the next forward pass; master weights, optimizer state, BatchNorm / FDS buffers are shared
-        (``train.py --amp_switch_epoch``)."""
+        (float32 activations and weights on the float32 kernels, in the arithmetic ``f32_arith``: "exact" / "x3" / "x2"; None keeps the current one).
+        Takes effect at the next forward pass; master weights, optimizer state, BatchNorm / FDS buffers are shared (``train.py --amp_switch_epoch``)."""
         assert amp_dtype in (None, torch.bfloat16)
+        assert f32_arith in (None, "exact", "x3", "x2"), f32_arith
         self.amp_dtype = amp_dtype
+        if f32_arith is not None:
+            self.f32_arith = f32_arith
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, inputs, *args, **kwargs):
@@ -161,6 +168,10 @@ class DataParallelEngine(nn.Module):
             inputs = inputs.contiguous(memory_format=torch.channels_last)
         if self.amp_dtype is not None:
             with torch.autocast(device_type=inputs.device.type, dtype=self.amp_dtype):
+                out = self.module(inputs, *args, **kwargs)
+        elif self.f32_arith != "exact":
+            from .conv_f32 import arithmetic
+            with arithmetic(self.f32_arith):
                 out = self.module(inputs, *args, **kwargs)
         else:
             out = self.module(inputs, *args, **kwargs)

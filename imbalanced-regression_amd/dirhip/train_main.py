@@ -9,7 +9,7 @@ Differences from the reference, all on purpose:
     (``python -m torch.distributed.run --nproc-per-node N train.py ...``); with one process it is a plain wrapper;
   * the hot loop and the FDS epoch tail come from ``dirhip.train_loop`` (device-resident features, loss read
     back every ``print_freq`` steps instead of every step);
-  * extra, optional flags: ``--synthetic N`` (random images, no files needed), ``--amp {bf16,fp32}``,
+  * extra, optional flags: ``--synthetic N`` (random images, no files needed), ``--amp {bf16,fp32,fp32x3,fp32x2}``, ``--amp_early``,
     ``--max_steps`` (truncate epochs for smoke runs). ``tensorboard_logger`` is used when importable.
 """
 import argparse
@@ -83,10 +83,13 @@ def build_parser(dataset_default='imdb_wiki'):
     p.add_argument('--evaluate', action='store_true', help='evaluate only flag')
     # additions
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic samples (no image files)')
-    p.add_argument('--amp', type=str, default='bf16', choices=['bf16', 'fp32'], help='conv-stack precision')
-    p.add_argument('--amp_switch_epoch', type=int, default=None, help='precision schedule: epochs < E run the conv stack in float32 (the reference\'s '
-                   'arithmetic: exact-float32 MFMA tile kernels), epochs >= E in bf16 (--amp bf16). Measured on the val-MAE proxy: bf16 costs MAE only '
-                   'during the first third of a schedule (random initialisation, full learning rate); from a float32 start it trains to the same MAE')
+    p.add_argument('--amp', type=str, default='bf16', choices=['bf16', 'fp32', 'fp32x3', 'fp32x2'], help='conv-stack precision: bf16 MFMA (default); fp32 = exact '
+                   'float32 MFMA (the reference\'s arithmetic, the parity mode); fp32x3 / fp32x2 = float32 tensors on the bf16 matrix pipe with every operand split '
+                   'into three / two bf16 terms: float32-grade results (x3: at float32\'s own rounding noise; x2: 16 significand bits), 1.4x / 2x the speed of fp32')
+    p.add_argument('--amp_switch_epoch', type=int, default=None, help='precision schedule: epochs < E run the conv stack in float32 (--amp_early), epochs >= E '
+                   'in bf16 (--amp bf16). Measured on the val-MAE proxy: bf16 costs MAE only during the first part of a schedule (random initialisation, full '
+                   'learning rate); from a float32 start it trains to the same MAE')
+    p.add_argument('--amp_early', type=str, default='fp32', choices=['fp32', 'fp32x3', 'fp32x2'], help='arithmetic of the epochs before --amp_switch_epoch')
     p.add_argument('--max_steps', type=int, default=0, help='truncate every epoch to this many steps (0 = full)')
     p.add_argument('--gpu_augment', action='store_true', help='image files only: the DataLoader yields decoded, resized uint8 images and '
                    'RandomCrop / flip / ToTensor / Normalize run as one HIP kernel per batch (dir_augment_u8) instead of per image on the host')
@@ -387,8 +390,10 @@ def run(argv=None, dataset_default='imdb_wiki'):
     model = resnet50(fds=args.fds, bucket_num=args.bucket_num, bucket_start=args.bucket_start,
                      start_update=args.start_update, start_smooth=args.start_smooth,
                      kernel=args.fds_kernel, ks=args.fds_ks, sigma=args.fds_sigma, momentum=args.fds_mmt)
-    fp32_first = args.amp == 'fp32' or (args.amp_switch_epoch is not None and args.start_epoch < args.amp_switch_epoch)
-    model = DataParallelEngine(model.to(device), amp_dtype=None if fp32_first else torch.bfloat16, channels_last=True)
+    fp32_first = args.amp != 'bf16' or (args.amp_switch_epoch is not None and args.start_epoch < args.amp_switch_epoch)
+    arith_of = {'fp32': 'exact', 'fp32x3': 'x3', 'fp32x2': 'x2'}
+    f32_arith = arith_of[args.amp] if args.amp != 'bf16' else arith_of[args.amp_early]
+    model = DataParallelEngine(model.to(device), amp_dtype=None if fp32_first else torch.bfloat16, channels_last=True, f32_arith=f32_arith)
 
     if args.evaluate:
         assert args.resume, 'Specify a trained model using [args.resume]'
@@ -442,7 +447,7 @@ def run(argv=None, dataset_default='imdb_wiki'):
                 for aug in (locals().get('aug_train'), locals().get('aug_eval')):
                     if aug is not None:
                         aug.dtype = torch.float32 if want is None else torch.bfloat16
-                print(f"Epoch [{epoch}]: conv stack in {'float32' if want is None else 'bf16'} (--amp_switch_epoch {args.amp_switch_epoch})")
+                print(f"Epoch [{epoch}]: conv stack in {('float32' if model.f32_arith == 'exact' else 'float32 on split-bf16 ' + model.f32_arith) if want is None else 'bf16'} (--amp_switch_epoch {args.amp_switch_epoch})")
         train_loss = train(train_batches(epoch), steps_per_epoch, model, optimizer, epoch, args, store)
         val_loss_mse, val_loss_l1, val_loss_gmean = validate(eval_batches(val_set), n_val, model, args, train_labels=train_labels)
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIR_ABI_VERSION 3
+#define DIR_ABI_VERSION 4
 
 #define DIR_OK            0
 #define DIR_EINVAL       (-1)   /* bad argument (null pointer, non-positive size, ks even, ...) */
@@ -564,6 +564,12 @@ int dir_conv_f32_wgrad(const float* dy, const float* x, float* dw, int N, int H,
  * same MFMA); the weight gradients differ in their split-K boundaries.  DIR_EUNSUPPORTED: variant TILE on a geometry it does not take. */
 #define DIR_CONV_F32_GATHER 1
 #define DIR_CONV_F32_TILE 2
+/* ABI 4: the tile kernels with SPLIT-bf16 arithmetic on the bf16 matrix pipe — every float32 operand element split in registers into three
+ * (X3) or two (X2) bf16 terms, six (three) v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block instead of eight v_mfma_f32_32x32x2_f32:
+ * float32-GRADE results (X3: ~2^-23 per product, like float32's own rounding; X2: 16 significand bits), NOT bit-equal to the exact kernels.
+ * `train.py --amp fp32x3` / the first epochs of `--amp_switch_epoch` run on X3; the parity mode (`--amp fp32`) stays on the exact MFMA. */
+#define DIR_CONV_F32_TILE_X3 3
+#define DIR_CONV_F32_TILE_X2 4
 int dir_conv_f32_fwd_variant(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                              int stride, int pad, int variant, dir_stream_t stream);
 int dir_conv_f32_dgrad_variant(const float* dy, const float* w, const float* addend, const float* addend_s2,
@@ -578,6 +584,9 @@ int dir_conv_f32_fwd_stats(const float* x, const float* w, float* y, float* stat
                            int R, int S, int stride, int pad, dir_stream_t stream);
 int dir_conv_f32_wgrad_variant(const float* dy, const float* x, float* dw, int N, int H, int W, int Cin, int Cout, int R, int S,
                                int stride, int pad, void* workspace, size_t workspace_bytes, int variant, dir_stream_t stream);
+/* dir_conv_f32_fwd_stats with the kernel / arithmetic chosen (ABI 4): variant 0, DIR_CONV_F32_TILE, _TILE_X3 or _TILE_X2. */
+int dir_conv_f32_fwd_stats_variant(const float* x, const float* w, float* y, float* stats, int stats_rows, int N, int H, int W, int Cin, int Cout,
+                                   int R, int S, int stride, int pad, int variant, dir_stream_t stream);
 /* float32 NHWC pools of the parity mode: MaxPool2d(3, 2, 1) with an argmax byte (resnet.py:82,131) and the global
  * average pool (resnet.py:85,136-137; sequential window sum / HW like torch's AvgPool2d). */
 int dir_maxpool3x3s2_f32_fwd(const float* x, float* y, void* argmax, int N, int H, int W, int C, dir_stream_t stream);

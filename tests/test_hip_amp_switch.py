@@ -42,7 +42,7 @@ def test_switch_from_float32_to_bf16_equals_a_bf16_engine_started_from_the_same_
         la = [train_step(eng, opt, xs[i], ys[i], w, 0, loss_fn).item() for i in (2, 3)]
         torch.cuda.synchronize()
     names = {e.key for e in prof.key_averages()}
-    assert any("conv_igemm" in n for n in names) and not any("conv_f32_tile_kernel<128, 128, 0>" in n for n in names), sorted(names)[:10]
+    assert any("conv_igemm" in n for n in names) and not any("conv_f32_tile_kernel<128, 128, 0," in n for n in names), sorted(names)[:10]
     # ---- the same two steps on a bf16 engine that starts from the snapshot
     torch.manual_seed(99)
     eng_b = DataParallelEngine(_model(), amp_dtype=torch.bfloat16, channels_last=True)

@@ -37,7 +37,7 @@ def load_tables(F, g, prefix):
 
 def test_library_loaded_is_in_tree():
     from dirhip import _lib
-    assert _lib.lib().dir_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().dir_abi_version() == _lib.ABI_VERSION == 4
     assert "imbalanced-regression_amd/dirhip/libdir_hip.so" in _lib.LIB_PATH
 
 

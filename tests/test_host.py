@@ -37,7 +37,7 @@ def test_cabi_exports_every_declared_symbol():
     assert tools_declared == set(toolslib.SIGNATURES) and not (tools_declared & declared)
     th = ctypes.CDLL(toolslib.LIB_PATH)
     assert all(hasattr(th, n) for n in tools_declared)
-    assert _lib.lib().dir_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().dir_abi_version() == _lib.ABI_VERSION == 4
     assert _lib.lib().dir_error_string(-1) == b"invalid argument"
 
 
