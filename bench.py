@@ -27,8 +27,8 @@ gpurun_out/bench_detail.json. After the timed region, rank 0 at N=1 also measure
     an HBM-resident size, the NYUD2 narrow-row scatter, each with algorithmic bytes / FLOPs from SURVEY.md §8d;
   * `roofline_step` — the per-step floor (sum of per-kernel rooflines) at nominal and measured peaks;
   * `cpu_baseline` — the reference's own loop (or its pinned torch-CPU port where /root/reference is absent) on the host cores at B=8.
-`--extras` (minutes; tools/bench_extras.py) adds to the detail file: every conv shape alone (`conv_layers`), all FDS shapes, the float32 / x3
-modes, the real-file input pipeline, the vendor-library step, the CPU micro-baselines.
+`--extras` (minutes; tools/bench_extras.py) adds to the detail file: every conv shape alone (`conv_layers`), all FDS shapes, the float32 modes (exact / split-bf16 x3 / x2),
+the real-file input pipeline, the vendor-library step, the CPU micro-baselines.
 """
 import argparse
 import ctypes
@@ -517,8 +517,8 @@ def main():
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"], help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo), to run the N > 1 "
                     "control flow on a one-GPU box; the throughput it prints is meaningless")
-    ap.add_argument("--extras", action="store_true", help="rank 0 also runs tools/bench_extras.py (every conv layer alone, all FDS shapes, float32 / x3 "
-                    "modes, input pipeline, vendor-library step, CPU micro-baselines: minutes) and writes them to the detail file")
+    ap.add_argument("--extras", action="store_true", help="rank 0 also runs tools/bench_extras.py (every conv layer alone, all FDS shapes, float32 modes (exact / split x3 / x2), "
+                    " input pipeline, vendor-library step, CPU micro-baselines: minutes) and writes them to the detail file")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the untrimmed result goes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")

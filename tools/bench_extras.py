@@ -413,17 +413,20 @@ def library_baseline(batch, timeout_s=240):
             "batch": batch, "ms_per_train_step": ms, "images_per_sec": batch / ms * 1e3, "first_step_s": steps[0] / 1e3, "wall_s": time.perf_counter() - t0}
 
 
-def float32_mode_probe(device, args, loss_fn):
-    """The parity-exact configuration next to the benchmarked one: the SAME loop with `amp_dtype=None` — the whole
+def float32_mode_probe(device, args, loss_fn, f32_arith="exact"):
+    """``f32_arith`` "exact": the parity-exact configuration next to the benchmarked one: the SAME loop with `amp_dtype=None` — the whole
     network on the exact-float32 MFMA kernels (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s = 1/16 of bf16), the mode that meets
     north_star's 1e-5 loss bar — timed over a few steps, and its step-0 loss at B=256 against the reference's own float32 CPU run
-    (tests/golden/step0_b256.npz, written by tests/golden/gen_golden_r3.py from the reference; inputs regenerated from its seeds)."""
+    (tests/golden/step0_b256.npz, written by tests/golden/gen_golden_r3.py from the reference; inputs regenerated from its seeds).
+    "x3" / "x2" (round 6): the same float32 graph with the conv stack on the split-bf16 kernels (`train.py --amp fp32x3 | fp32x2`)."""
     from dirhip import resnet as R
     from dirhip.loss import weighted_l1_loss
     from dirhip.optim import Adam
     from dirhip.parallel import DataParallelEngine
     from dirhip.train_loop import EpochFeatures
-    out = {"amp_dtype": None, "kernels": "dir_conv_f32_* (exact float32 MFMA), same fused autograd graph as the bf16 path"}
+    out = {"amp_dtype": None, "f32_arith": f32_arith,
+           "kernels": ("dir_conv_f32_* (exact float32 MFMA)" if f32_arith == "exact" else
+                       f"dir_conv_f32_* tile kernels, split-bf16 {f32_arith} ({'6' if f32_arith == 'x3' else '3'} x v_mfma_f32_32x32x16_bf16 per block)") + ", same fused autograd graph as the bf16 path"}
     gpath = os.path.join(ROOT, "tests", "golden", "step0_b256.npz")
     if os.path.isfile(gpath):
         g = np.load(gpath, allow_pickle=False)
@@ -437,7 +440,7 @@ def float32_mode_probe(device, args, loss_fn):
         torch.manual_seed(cfg["seed_model"])
         model = R.resnet50(fds=True, bucket_num=cfg["bucket_num"], bucket_start=cfg["bucket_start"], start_update=cfg["start_update"],
                            start_smooth=cfg["start_smooth"], kernel=cfg["kernel"], ks=cfg["ks"], sigma=cfg["sigma"], momentum=cfg["momentum"]).to(device)
-        eng = DataParallelEngine(model, amp_dtype=None, channels_last=True)
+        eng = DataParallelEngine(model, amp_dtype=None, channels_last=True, f32_arith=f32_arith)
         eng.train()
         for ep in range(2):
             rr = np.random.default_rng(cfg["seed_fds"] + ep)
@@ -461,6 +464,7 @@ def float32_mode_probe(device, args, loss_fn):
     args.epoch_len = epoch_len
     try:
         model, engine, optimizer, batches = build(args, device, 0, amp_dtype=None)
+        engine.set_amp_dtype(None, f32_arith=f32_arith)
     finally:
         args.epoch_len, = saved
     store = EpochFeatures(epoch_len * args.batch, 2048, device)
@@ -497,6 +501,8 @@ def run_all(result, device, args, loss_fn, dt_train):
                 "note": "isolated launches, inputs rotated over > 256 MB of distinct buffers; roofline_us = max(FLOP / 2.5 PF, bytes / 8 TB/s)"}
     leg("conv_layers", layers)
     leg("float32_mode", lambda: float32_mode_probe(device, args, loss_fn))
+    leg("float32_x3_mode", lambda: float32_mode_probe(device, args, loss_fn, "x3"))
+    leg("float32_x2_mode", lambda: float32_mode_probe(device, args, loss_fn, "x2"))
     leg("input_pipeline", lambda: input_pipeline_probe(device, result["value"], args.batch, n_gpus_target=8))
 
     def library():

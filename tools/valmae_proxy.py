@@ -18,6 +18,9 @@ Adam arithmetic, the initial weights and the batch order per seed. Deltas are pa
 buffers, Adam moments); every arm then trains the remaining epochs from it with the same batch order per seed, so the arms differ by their
 arithmetic over the converging phase only and the paired difference is not buried under the chaotic divergence of whole trajectories.
 
+Round 6, split arithmetics: arms ``fp32x3`` / ``fp32x2`` (whole schedule on the split-bf16 kernels) and ``mixed<E>x3`` / ``mixed<E>x2`` (split arithmetic for
+epochs < E, bf16 after) — `train.py --amp fp32x2`, `--amp_switch_epoch E --amp_early fp32x2`.
+
 Round 6: arm ``mixed<E>`` = the product's precision schedule (`train.py --amp_switch_epoch E`): ONE engine, float32 tile kernels for
 epochs < E, bf16 from epoch E on; its first E epochs are bit-identical to the ``float32`` arm's (deterministic kernels, same seed), so the paired
 difference measures exactly what the switch costs.
@@ -68,11 +71,17 @@ def make_task(device, n_train, n_val, seed=1234):
     return y_train, y_val, images(y_train, seed + 1), images(y_val, seed + 2)
 
 
-ARMS = ("bf16", "float32", "lib_f32", "lib_bf16")
+ARMS = ("bf16", "float32", "fp32x3", "fp32x2", "lib_f32", "lib_bf16")
 
 
 def switch_epoch_of(arm):
-    return int(arm[5:]) if arm.startswith("mixed") else None
+    """``mixed<E>`` / ``mixed<E>x3`` / ``mixed<E>x2``: float32 (exact / split-bf16 x3 / x2) for epochs < E, bf16 after."""
+    return int(arm[5:].split("x")[0]) if arm.startswith("mixed") else None
+
+
+def arith_of(arm):
+    """Arithmetic of the arm's float32 epochs: "exact" (float32, mixed<E>), "x3" / "x2" (fp32x3 / fp32x2, mixed<E>x3 / mixed<E>x2)."""
+    return "x3" if arm.endswith("x3") else ("x2" if arm.endswith("x2") else "exact")
 
 
 def build_arm(arm, seed, device, init_state=None):
@@ -84,8 +93,8 @@ def build_arm(arm, seed, device, init_state=None):
     model = resnet50(fds=True, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
     if init_state is not None:
         model.load_state_dict(init_state["model"])
-    if arm in ("bf16", "float32") or arm.startswith("mixed"):
-        eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if arm == "bf16" else None, channels_last=True)
+    if arm in ("bf16", "float32", "fp32x3", "fp32x2") or arm.startswith("mixed"):
+        eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if arm == "bf16" else None, channels_last=True, f32_arith=arith_of(arm))
         opt = Adam(eng.parameters(), lr=1e-3)
     else:
         from library_resnet import AutocastModel, LibraryResNet50
@@ -202,7 +211,10 @@ def main():
            "arms": {"bf16": "the product path (this repo's bf16 graph)", "float32": "the product's parity-exact float32 mode",
                     "lib_f32": "the reference's arithmetic on this GPU: plain torch modules, vendor-library float32 kernels (tools/library_resnet.py)",
                     "lib_bf16": "the same library network under torch.autocast(bfloat16)",
-                    **{x: f"the product's precision schedule (train.py --amp_switch_epoch {switch_epoch_of(x)}): float32 tile kernels for epochs < {switch_epoch_of(x)}, bf16 after"
+                    "fp32x3": "the product's float32 graph on the split-bf16 x3 kernels (train.py --amp fp32x3)",
+                    "fp32x2": "the product's float32 graph on the split-bf16 x2 kernels (train.py --amp fp32x2)",
+                    **{x: f"the product's precision schedule (train.py --amp_switch_epoch {switch_epoch_of(x)} --amp_early {'fp32' if arith_of(x) == 'exact' else 'fp32' + arith_of(x)}): "
+                          f"float32 tile kernels ({arith_of(x)}) for epochs < {switch_epoch_of(x)}, bf16 after"
                        for x in arms if x.startswith("mixed")}},
            "form": (f"branch: every arm continues ONE {a.ref} run from epoch {a.branch} (weights, buffers, Adam moments), same batch order per seed" if a.branch
                     else "whole schedules, same initial weights and batch order per seed"),
