@@ -230,10 +230,9 @@ __global__ void __launch_bounds__(DIR_TPB) conv_f32_wgrad_reduce_kernel(const fl
 // stay on the gather kernels.
 constexpr int FT_BK = 16, FT_ROWB = FT_BK * 4;
 constexpr int FT_OOB = (int)0x80000000;
-constexpr int FT_SPLIT_PIPE_ON = 1;      // split arithmetics: software-pipelined K loop (terms of K-step it + 1 prepared under the MFMAs of K-step it; three stages)
-constexpr bool FT_SPLIT_PIPE(int arith) { return arith != 0 && FT_SPLIT_PIPE_ON != 0; }
-constexpr int FT_SPLIT_STAGES = FT_SPLIT_PIPE_ON ? 3 : 2;      // ring depth of the split-bf16 arithmetics: a K-step of 16 is ~0.2 us of their matrix work, less than one L2 round trip,
-                                        // so FT_SPLIT_STAGES - 1 K-steps stay in flight (counted s_waitcnt, one barrier per K-step)
+constexpr int FT_SPLIT_STAGES = 2;      // LDS stages of the split-bf16 arithmetics. The loop below is a ring with counted s_waitcnt (FT_SPLIT_STAGES - 1 K-steps in flight
+                                        // across the barrier); measured at 2 / 3 / 4 stages: 33.8 / 35.9 / 38.3 ms over the step's layers (x2) - the loop is not bound by
+                                        // the DMA's latency, so two stages = the most workgroups per CU (profiles/r06_f32_split_arith.txt)
 constexpr int FT_ABLATE = 0;            // measurement builds only (tools/ablate_f32.py patches this line): 1 = no DMA, 2 = no epilogue stores, 3 = no MFMA, 4 = no barriers / DMA waits, 5 = (split arithmetics) no split VALU work
 enum { FT_FWD = 0, FT_DGRAD = 1, FT_WGRAD = 2 };
 
@@ -263,10 +262,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
 // terms is that of the last rounding, 2^-24 of the element, unbiased; 0.5 instead of 1.5 conversions per element. TWO terms: both rounded to nearest
 // (truncating the leading term doubles the error, 2^-16 instead of 2^-17, for 3 % of the time).
 constexpr int FT_X2_WAVES = 4;         // wavefronts per SIMD the two-term kernels are compiled for (their natural allocation is 130-147 registers = 3)
-constexpr int FT_X3_WGRAD_WAVES = 2;    // three terms, data / weight gradient (k-major operands: 8 four-byte fragment reads each): > 168 registers when pipelined
-constexpr int FT_WAVES(int arith, int mode) {      // (three LDS stages = three workgroups per CU)
-    return arith == 2 ? (FT_SPLIT_PIPE_ON ? 3 : FT_X2_WAVES) : (arith == 3 ? ((FT_SPLIT_PIPE_ON && mode != 0) ? FT_X3_WGRAD_WAVES : 3) : 4);
-}
+constexpr int FT_WAVES(int arith) { return arith == 2 ? FT_X2_WAVES : (arith == 3 ? 3 : 4); }
 constexpr bool FT_SPLIT_RNE_HI(int nt) { return nt == 2; }
 template <int NT>
 __device__ __forceinline__ void ft_split(cf_f32x8 v, cf_bf16x8 (&t)[NT]) {
@@ -292,32 +288,8 @@ __device__ __forceinline__ void ft_split(cf_f32x8 v, cf_bf16x8 (&t)[NT]) {
     t[NT - 1] = __builtin_convertvector(v, cf_bf16x8);                       // v_cvt_pk_bf16_f32: round to nearest even
 }
 
-// One PAIR of elements (the unit the software-pipelined K loop interleaves with the MFMAs): v0, v1 -> dword j of each term.
-template <int NT>
-__device__ __forceinline__ void ft_split_pair(float v0, float v1, uint32_t (&t)[NT]) {
-#pragma unroll
-    for (int s = 0; s + 1 < NT; ++s) {
-        uint32_t pk, h0, h1;
-        if (FT_SPLIT_RNE_HI(NT)) {
-            typedef __attribute__((ext_vector_type(2))) float f32x2_;
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-            pk = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){v0, v1}, bf16x2_));
-            h0 = pk << 16; h1 = pk & 0xffff0000u;
-        } else {
-            const uint32_t b0 = __builtin_bit_cast(uint32_t, v0), b1 = __builtin_bit_cast(uint32_t, v1);
-            pk = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-            h0 = b0 & 0xffff0000u; h1 = b1 & 0xffff0000u;
-        }
-        t[s] = pk;
-        v0 -= __builtin_bit_cast(float, h0); v1 -= __builtin_bit_cast(float, h1);      // exact
-    }
-    typedef __attribute__((ext_vector_type(2))) float f32x2_;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-    t[NT - 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){v0, v1}, bf16x2_));
-}
-
 template <int TM, int TN, int MODE, int ARITH = 0>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT_WAVES(ARITH, MODE)))) conv_f32_tile_kernel(ConvF32T q) {
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT_WAVES(ARITH)))) conv_f32_tile_kernel(ConvF32T q) {
     const ConvF32P& p = q.c;
     constexpr bool AKM = MODE == FT_WGRAD, BKM = MODE != FT_FWD;
     constexpr int WGM = (TM == 128 && TN == 64) ? 4 : 2, WGN = 4 / WGM;
@@ -528,9 +500,10 @@ __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT
     // Split-bf16 K-step (ARITH 2 / 3): lane (fi, fh) takes the EIGHT k = 8 fh .. 8 fh + 7 of its row (K-contiguous tiles: two ds_read_b128, the
     // chunks 2 fh and 2 fh + 1; k-major tiles: eight ds_read_b32) as element i of the bf16 fragments — the same k <-> element map for both operands.
     // Term pairs in ascending magnitude, the four accumulator tiles interleaved (no two consecutive MFMAs on one accumulator).
-    constexpr int NT = ARITH == 3 ? 3 : 2;                            // (ARITH 0: unused)
-    auto load_split = [&](int stage, cf_bf16x8 (&at)[MI][NT], cf_bf16x8 (&bt)[NI][NT]) {
+    auto mfma_step_split = [&](int stage) {
+        constexpr int NT = ARITH == 3 ? 3 : 2;
         const unsigned char* sbase = smem + stage * STAGE;
+        cf_bf16x8 at[MI][NT], bt[NI][NT];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             cf_f32x8 v;
@@ -560,8 +533,6 @@ __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT
             if (FT_ABLATE == 5) { for (int s_ = 0; s_ < NT; ++s_) bt[ni][s_] = __builtin_bit_cast(cf_bf16x8, (cf_f32x4){v[s_], v[s_ + 1], v[s_ + 2], v[s_ + 3]}); }
             else ft_split<NT>(v, bt[ni]);
         }
-    };
-    auto mfma_terms = [&](const cf_bf16x8 (&at)[MI][NT], const cf_bf16x8 (&bt)[NI][NT]) {
         // (term of A, term of B), smallest products first; index NT - 1 = lo, 0 = hi
         constexpr int NP = ARITH == 3 ? 6 : 3;
         constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
@@ -576,11 +547,6 @@ __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT
                     if (FT_ABLATE == 3) asm volatile("" :: "v"(at[mi][ta]), "v"(bt[ni][tb]));
                     else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[mi][ta], bt[ni][tb], acc[mi][ni], 0, 0, 0);
         }
-    };
-    auto mfma_step_split = [&](int stage) {
-        cf_bf16x8 at[MI][NT], bt[NI][NT];
-        load_split(stage, at, bt);
-        mfma_terms(at, bt);
     };
 
     int stage = 0;
@@ -598,100 +564,6 @@ __global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT
                 }
                 stage ^= 1;
             }
-        }
-    } else if (FT_SPLIT_PIPE(ARITH)) {
-        // Software pipeline over THREE stages: while the matrix pipe works through the products of K-step it (terms in registers), the wavefront reads and
-        // splits the fragments of K-step it + 1 (LDS latency and ~100 VALU operations under 12-24 MFMAs), and the DMA of K-step it + 2 is in flight.
-        // The barrier of iteration it says: everyone's pieces of stage it + 1 have landed, and everyone has read stage it (during iteration it - 1) - which is
-        // not the stage the next issue overwrites ((it + 2) % 3 = (it - 1) % 3, read during iteration it - 2).
-        static_assert(!FT_SPLIT_PIPE(ARITH) || NS == 3, "the software pipeline uses three LDS stages");
-        constexpr int PIECES = NA + NB;
-        if (nsteps > 0) {
-            issue(0, kbeg);
-            if (nsteps > 1) issue(1, kbeg + FT_BK);
-            if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory"); else cp_dma_wait();
-            __syncthreads();
-            // terms of the current K-step as dwords: tc[fragment][term][pair]; fragments 0 .. MI - 1 = A row blocks, MI .. = B column blocks
-            constexpr int NF = MI + NI, NCH = 4 * NF, NP = ARITH == 3 ? 6 : 3, NMF = NP * MI * NI;
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
-            uint32_t tc[NF][NT][4];
-            float raw[NF][8];
-            auto load_raw = [&](int stage) {
-                const unsigned char* sbase = smem + stage * STAGE;
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const bool km = f < MI ? AKM : BKM;
-                    const uint32_t fo = f < MI ? afo[f] : bfo[f - MI];
-                    const int T = f < MI ? TM : TN;
-                    if (!km) {
-                        const float4 lo4 = *reinterpret_cast<const float4*>(sbase + fo + (((uint32_t)(2 * fh) ^ aswz) << 4));
-                        const float4 hi4 = *reinterpret_cast<const float4*>(sbase + fo + (((uint32_t)(2 * fh + 1) ^ aswz) << 4));
-                        raw[f][0] = lo4.x; raw[f][1] = lo4.y; raw[f][2] = lo4.z; raw[f][3] = lo4.w;
-                        raw[f][4] = hi4.x; raw[f][5] = hi4.y; raw[f][6] = hi4.z; raw[f][7] = hi4.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) raw[f][i] = *reinterpret_cast<const float*>(sbase + fo + (7 * fh + i) * (T * 4));
-                    }
-                }
-            };
-            load_raw(0);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                uint32_t t_[NT];
-                ft_split_pair<NT>(raw[c / 4][2 * (c % 4)], raw[c / 4][2 * (c % 4) + 1], t_);
-#pragma unroll
-                for (int s_ = 0; s_ < NT; ++s_) tc[c / 4][s_][c % 4] = t_[s_];
-            }
-            int s_next = 1, s_issue = 2;
-            for (int it = 0; it + 1 < nsteps; ++it) {                   // (the last K-step's products: after the loop — the body has ONE path)
-                cp_dma_wait();                                          // K-step it + 1 is the youngest issued
-                __syncthreads();
-                if (it + 2 < nsteps) { issue(s_issue, kbeg + (it + 2) * FT_BK); s_issue = s_issue == 2 ? 0 : s_issue + 1; }
-                load_raw(s_next); s_next = s_next == 2 ? 0 : s_next + 1;
-                // The issue order is PINNED (sched_barrier): the fragment reads of K-step it + 1, then one MFMA of K-step it followed by the split of one
-                // element pair of K-step it + 1 (6-11 VALU operations = the ~32 clocks the MFMA holds the matrix pipe), repeated. hipcc's own schedule — also
-                // under sched_group_barrier requests — issues the MFMAs in clumps of 8-24 (the wavefront then waits in the pipe's queue) and the VALU work after them.
-                uint32_t tn[NF][NT][4];
-                constexpr int LEAD = 2;                                  // MFMAs ahead of the first split (the fragment reads are still in flight)
-#pragma unroll
-                for (int g_ = 0; g_ < (NMF > NCH + LEAD ? NMF : NCH + LEAD); ++g_) {
-                    if (g_ < NMF) {
-                        const int pi = g_ / (MI * NI), mi = (g_ / NI) % MI, ni = g_ % NI;
-                        const int ta = ARITH == 3 ? PA3[pi] : PA2[pi], tb = ARITH == 3 ? PB3[pi] : PB2[pi];
-                        const cf_bf16x8 av = __builtin_bit_cast(cf_bf16x8, (u32x4_){tc[mi][ta][0], tc[mi][ta][1], tc[mi][ta][2], tc[mi][ta][3]});
-                        const cf_bf16x8 bv = __builtin_bit_cast(cf_bf16x8, (u32x4_){tc[MI + ni][tb][0], tc[MI + ni][tb][1], tc[MI + ni][tb][2], tc[MI + ni][tb][3]});
-                        if (FT_ABLATE == 3) asm volatile("" :: "v"(av), "v"(bv));
-                        else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (g_ >= LEAD && g_ - LEAD < NCH) {
-                        const int c = g_ - LEAD;
-                        uint32_t t_[NT];
-                        ft_split_pair<NT>(raw[c / 4][2 * (c % 4)], raw[c / 4][2 * (c % 4) + 1], t_);
-#pragma unroll
-                        for (int s_ = 0; s_ < NT; ++s_) tn[c / 4][s_][c % 4] = t_[s_];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int s_ = 0; s_ < NT; ++s_)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tc[f][s_][j] = tn[f][s_][j];
-            }
-#pragma unroll
-            for (int g_ = 0; g_ < NMF; ++g_) {
-                const int pi = g_ / (MI * NI), mi = (g_ / NI) % MI, ni = g_ % NI;
-                const int ta = ARITH == 3 ? PA3[pi] : PA2[pi], tb = ARITH == 3 ? PB3[pi] : PB2[pi];
-                const cf_bf16x8 av = __builtin_bit_cast(cf_bf16x8, (u32x4_){tc[mi][ta][0], tc[mi][ta][1], tc[mi][ta][2], tc[mi][ta][3]});
-                const cf_bf16x8 bv = __builtin_bit_cast(cf_bf16x8, (u32x4_){tc[MI + ni][tb][0], tc[MI + ni][tb][1], tc[MI + ni][tb][2], tc[MI + ni][tb][3]});
-                if (FT_ABLATE == 3) asm volatile("" :: "v"(av), "v"(bv));
-                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
-            }
-            __syncthreads();                                            // the epilogue reuses the stages' LDS
         }
     } else {
         // ring of NS stages, NS - 1 K-steps in flight: the wavefront's pieces land in issue order, so "all but the youngest (NS - 2) K-steps' pieces"

@@ -77,6 +77,16 @@ def test_train_py_cli_precision_schedule(tmp_path):
     assert "conv stack in float32" not in out and "Epoch [2]: conv stack in bf16" in out and "Epoch #2: Train loss" in out, out[-2000:]
 
 
+def test_train_py_cli_split_bf16_arithmetic(tmp_path):
+    """train.py --amp fp32x2 (whole run on the split-bf16 float32 kernels) and --amp_switch_epoch 1 --amp_early fp32x3 (split arithmetic first, bf16 after)."""
+    common = ["--synthetic", "256", "--fds", "--lds", "--reweight", "sqrt_inv", "--batch_size", "64", "--print_freq", "4"]
+    out = _cli(common + ["--store_root", str(tmp_path / "a"), "--amp", "fp32x2", "--epoch", "1"], "cli_fp32x2.log")
+    assert "Epoch #0: Train loss" in out and "Test loss: MSE" in out and "conv stack in" not in out
+    out = _cli(common + ["--store_root", str(tmp_path / "b"), "--amp_switch_epoch", "1", "--amp_early", "fp32x3", "--epoch", "2"], "cli_amp_early.log")
+    assert "Epoch [0]: conv stack in float32 on split-bf16 x3 (--amp_switch_epoch 1)" in out and "Epoch [1]: conv stack in bf16 (--amp_switch_epoch 1)" in out, out[-2000:]
+    assert "Epoch #1: Train loss" in out
+
+
 def test_train_py_cli_on_image_files_host_and_gpu_augment(tmp_path):
     """The real-data path of the drop-in CLI, executed: an agedb-style csv + image files (written here), DataLoader workers, the
     host transform chain — the same run with --gpu_augment (uint8 batches, dir_augment_u8 on the GPU) — and with
