@@ -71,7 +71,7 @@ def make_task(device, n_train, n_val, seed=1234):
     return y_train, y_val, images(y_train, seed + 1), images(y_val, seed + 2)
 
 
-ARMS = ("bf16", "float32", "fp32x3", "fp32x2", "lib_f32", "lib_bf16")
+ARMS = ("bf16", "float32", "float32_sepstats", "fp32x3", "fp32x2", "lib_f32", "lib_bf16")
 
 
 def switch_epoch_of(arm):
@@ -93,7 +93,7 @@ def build_arm(arm, seed, device, init_state=None):
     model = resnet50(fds=True, bucket_num=100, bucket_start=3, start_update=0, start_smooth=1, kernel="gaussian", ks=5, sigma=2, momentum=0.9).to(device)
     if init_state is not None:
         model.load_state_dict(init_state["model"])
-    if arm in ("bf16", "float32", "fp32x3", "fp32x2") or arm.startswith("mixed"):
+    if arm in ("bf16", "float32", "float32_sepstats", "fp32x3", "fp32x2") or arm.startswith("mixed"):
         eng = DataParallelEngine(model, amp_dtype=torch.bfloat16 if arm == "bf16" else None, channels_last=True, f32_arith=arith_of(arm))
         opt = Adam(eng.parameters(), lr=1e-3)
     else:
@@ -193,6 +193,12 @@ def main():
     for seed in range(a.seed0, a.seed0 + a.seeds):
         for arm in arms:
             t1 = time.time()
+            # float32_sepstats: the float32 graph with the BatchNorm statistics from a separate pass over y (the build before the float32 tile kernels formed them
+            # in their store loop): the same arithmetic class, another float32 summation order — the arm that measures what the proxy can resolve
+            import dirhip.conv_f32 as _cf
+            if not hasattr(_cf, "_stats_fusable_product"):
+                _cf._stats_fusable_product = _cf.stats_fusable
+            _cf.stats_fusable = (lambda x, w: False) if arm == "float32_sepstats" else _cf._stats_fusable_product
             eng, opt = build_arm(arm, seed if not a.branch else 1000, device, init_state=start)
             train_epochs(eng, opt, task, seed, a.branch, a.epochs, a.batch, a.decay_at, switch_epoch=switch_epoch_of(arm))
             r = evaluate(eng, task, a.batch)
@@ -211,6 +217,7 @@ def main():
            "arms": {"bf16": "the product path (this repo's bf16 graph)", "float32": "the product's parity-exact float32 mode",
                     "lib_f32": "the reference's arithmetic on this GPU: plain torch modules, vendor-library float32 kernels (tools/library_resnet.py)",
                     "lib_bf16": "the same library network under torch.autocast(bfloat16)",
+                    "float32_sepstats": "float32 with the BatchNorm statistics from a separate pass (the build before commit 1521e9c): same arithmetic class, other summation order",
                     "fp32x3": "the product's float32 graph on the split-bf16 x3 kernels (train.py --amp fp32x3)",
                     "fp32x2": "the product's float32 graph on the split-bf16 x2 kernels (train.py --amp fp32x2)",
                     **{x: f"the product's precision schedule (train.py --amp_switch_epoch {switch_epoch_of(x)} --amp_early {'fp32' if arith_of(x) == 'exact' else 'fp32' + arith_of(x)}): "
