@@ -476,6 +476,9 @@ def float32_mode_probe(device, args, loss_fn, f32_arith="exact"):
                 "train_only_ms_per_step": dt_train / steps * 1e3, "steps": steps, "batch": args.batch,
                 "achieved_TFLOPs_train_only": steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12, "peak_f32_mfma_TFLOPs": 157.3,
                 "frac_of_f32_mfma_peak_train_only": steps * args.batch * FLOP_FWD_BWD / dt_train / 1e12 / 157.3})
+    if f32_arith != "exact":
+        out["note"] = ("split-bf16 arithmetic runs on the bf16 matrix pipe (6 / 3 MFMAs per block): `frac_of_f32_mfma_peak_train_only` is the speed relative to the "
+                       "float32 MFMA peak, not a utilisation of it")
     del model, engine, optimizer, batches, store
     torch.cuda.empty_cache()
     return out
