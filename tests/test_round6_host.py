@@ -90,3 +90,49 @@ def test_value_groups_equal_the_reference_row_groups():
         gid2, bin_ptr2, ng2 = value_groups(labels, start, num, all_labels=both)
         gid_all, _, ng_all = value_groups(both, start, num)
         assert ng2 == ng_all and np.array_equal(gid2, gid_all[:labels.size])
+
+
+def test_float32_arithmetic_scope_is_thread_local_nested_and_restored():
+    """conv_f32.arithmetic(name): the arithmetic of the float32 conv nodes built inside the scope (round 6, ABI 4: exact / split-bf16 x3 / x2). No process-wide
+    switch: the scope is thread-local, nests, and is restored when the block is left by an exception; the engine / CLI only accept the three names."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "imbalanced-regression_amd"))
+    import pytest
+    from dirhip import conv_f32 as c
+    assert c.current_arith() == 0 and c.ARITHMETICS == {"exact": 0, "x3": 3, "x2": 4}
+    with c.arithmetic("x3"):
+        assert c.current_arith() == c.TILE_X3
+        with c.arithmetic("x2"):
+            assert c.current_arith() == c.TILE_X2
+            with c.arithmetic(None):
+                assert c.current_arith() == 0
+            assert c.current_arith() == c.TILE_X2
+        assert c.current_arith() == c.TILE_X3
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(c.current_arith()))       # another thread (autograd's, a prefetcher's) is outside the scope
+        t.start(); t.join()
+        assert seen == [0]
+    with pytest.raises(RuntimeError):
+        with c.arithmetic("x2"):
+            raise RuntimeError("boom")
+    assert c.current_arith() == 0
+    with pytest.raises(KeyError):
+        with c.arithmetic("x4"):
+            pass
+    # header, ctypes table and CLI agree on the new names
+    hdr = open(os.path.join(ROOT, "include", "dir_hip.h")).read()
+    assert "#define DIR_CONV_F32_TILE_X3 3" in hdr and "#define DIR_CONV_F32_TILE_X2 4" in hdr and "#define DIR_ABI_VERSION 4" in hdr
+    from dirhip import _lib
+    assert "dir_conv_f32_fwd_stats_variant" in _lib.SIGNATURES and _lib.ABI_VERSION == 4
+    src = open(os.path.join(ROOT, "imbalanced-regression_amd", "dirhip", "train_main.py")).read()
+    assert "choices=['bf16', 'fp32', 'fp32x3', 'fp32x2']" in src and "'--amp_early'" in src
+    from dirhip.parallel import DataParallelEngine
+    import torch
+    eng = DataParallelEngine(torch.nn.Linear(2, 2), amp_dtype=None, f32_arith="x2")
+    assert eng.f32_arith == "x2"
+    eng.set_amp_dtype(torch.bfloat16)
+    assert eng.f32_arith == "x2" and eng.amp_dtype == torch.bfloat16            # the float32 arithmetic is kept across a bf16 phase
+    eng.set_amp_dtype(None, f32_arith="exact")
+    assert eng.f32_arith == "exact"
+    with pytest.raises(AssertionError):
+        DataParallelEngine(torch.nn.Linear(2, 2), f32_arith="x4")
