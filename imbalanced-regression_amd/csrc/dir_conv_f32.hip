@@ -262,7 +262,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
 // terms is that of the last rounding, 2^-24 of the element, unbiased; 0.5 instead of 1.5 conversions per element. TWO terms: both rounded to nearest
 // (truncating the leading term doubles the error, 2^-16 instead of 2^-17, for 3 % of the time).
 constexpr int FT_X2_WAVES = 4;         // wavefronts per SIMD the two-term kernels are compiled for (their natural allocation is 130-147 registers = 3)
-constexpr int FT_WAVES(int arith) { return arith == 2 ? FT_X2_WAVES : (arith == 3 ? 3 : 4); }
+constexpr int FT_WAVES(int arith, int mode) { return arith == 2 ? (mode == 2 ? 3 : FT_X2_WAVES) : (arith == 3 ? 3 : 4); }   // (x2 weight gradient, k-major operands: 4 would spill)
 constexpr bool FT_SPLIT_RNE_HI(int nt) { return nt == 2; }
 template <int NT>
 __device__ __forceinline__ void ft_split(cf_f32x8 v, cf_bf16x8 (&t)[NT]) {
@@ -289,7 +289,7 @@ __device__ __forceinline__ void ft_split(cf_f32x8 v, cf_bf16x8 (&t)[NT]) {
 }
 
 template <int TM, int TN, int MODE, int ARITH = 0>
-__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT_WAVES(ARITH)))) conv_f32_tile_kernel(ConvF32T q) {
+__global__ void __launch_bounds__(DIR_TPB) __attribute__((amdgpu_waves_per_eu(FT_WAVES(ARITH, MODE)))) conv_f32_tile_kernel(ConvF32T q) {
     const ConvF32P& p = q.c;
     constexpr bool AKM = MODE == FT_WGRAD, BKM = MODE != FT_FWD;
     constexpr int WGM = (TM == 128 && TN == 64) ? 4 : 2, WGN = 4 / WGM;
